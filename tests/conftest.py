@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'soda-compiler_amd')):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+SAMPLES = os.path.join(ROOT, 'tests', 'samples')
+
+
+def pytest_configure(config):
+  config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+
+
+@pytest.fixture(scope='session')
+def golden_dir():
+  return GOLDEN
+
+
+@pytest.fixture(scope='session')
+def samples_dir():
+  return SAMPLES

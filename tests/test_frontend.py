@@ -1,0 +1,177 @@
+"""Front end vs. the reference's own analysis (tests/golden/analysis.json, made
+by tests/golden/make_golden.py from the real reference under python3.9)."""
+import glob
+import json
+import os
+
+import pytest
+
+from soda_hip import frontend
+from soda_hip.frontend import expr as ex
+from soda_hip.frontend.errors import SemanticError, SodaSyntaxError
+from soda_hip.frontend.types import c_type
+
+from conftest import GOLDEN, SAMPLES
+
+with open(os.path.join(GOLDEN, 'analysis.json')) as f:
+  ANALYSIS = json.load(f)
+
+
+def describe(stencil):
+  """Same shape as make_golden.analysis_of(), from OUR analysis."""
+  stages = []
+  for inst in stencil.instances():
+    stage = inst['stage']
+    rename = inst['rename']
+
+    def load_text(ld, stage=stage, rename=rename):
+      rel = [a - b for a, b in zip(ld.idx, stage.st_idx)]
+      return '%s[%s]' % (rename[ld.name], ','.join(map(str, rel)))
+
+    loads = {}
+    for ld in stage.loads():
+      loads.setdefault(rename[ld.name], []).append(list(ld.idx))
+    stages.append(dict(
+        name=inst['name'], haoda_type=stage.haoda_type,
+        c_type=c_type(stage.haoda_type), st_idx=list(stage.st_idx),
+        expr_str=ex.soda_text(ex.rename_loads(stage.expr, rename.get)),
+        c_expr=ex.c_text(stage.expr, load_text, c_type),
+        loads=loads, loop_lo=list(inst['loop_lo']),
+        loop_hi_margin=list(inst['loop_hi_margin']),
+        is_output=inst['is_output']))
+  return stages
+
+
+@pytest.mark.parametrize('key', sorted(ANALYSIS))
+def test_analysis_matches_reference(key):
+  ref = ANALYSIS[key]
+  app, it = key.split('.iter')
+  st = frontend.load(os.path.join(SAMPLES, app + '.soda'), iterate=int(it))
+  assert st.app_name == ref['app_name']
+  assert st.dim == ref['dim']
+  assert list(st.tile_size) == ref['tile_size']
+  assert st.burst_width == ref['burst_width']
+  assert st.unroll_factor == ref['unroll_factor']
+  assert list(st.input_names) == ref['input_names']
+  assert list(st.local_names) == ref['local_names']
+  assert list(st.output_names) == ref['output_names']
+  ours = describe(st)
+  # execution order: inputs first, then instances, like chronological_tensors
+  assert list(st.input_names) + [s['name'] for s in ours] == ref['chronological']
+  assert len(ours) == len(ref['stages'])
+  for mine, theirs in zip(ours, ref['stages']):
+    for field in ('name', 'haoda_type', 'c_type', 'st_idx', 'expr_str', 'c_expr',
+                  'loop_lo', 'loop_hi_margin', 'is_output'):
+      assert mine[field] == theirs[field], (field, mine['name'])
+    # the reference sorts each parent's loads by linearised offset
+    # (core.py:389-395); compare as multisets per parent
+    assert {k: sorted(v) for k, v in mine['loads'].items()} == \
+        {k: sorted(v) for k, v in theirs['loads'].items()}
+  # STENCIL_DIM_n macros of the generated host (host.py:1183-1186)
+  lo, hi = ours[-1]['loop_lo'], ours[-1]['loop_hi_margin']
+  for d in range(st.dim):
+    assert ref['macros']['STENCIL_DIM_%d' % d] == lo[d] + hi[d] + 1
+
+
+def test_samples_all_parse():
+  files = sorted(glob.glob(os.path.join(SAMPLES, '*.soda')))
+  assert len(files) == 8
+  for path in files:
+    st = frontend.load(path)
+    assert st.stages
+
+
+def test_readme_example_any_key_order():
+  # header keys may come in any order and between statement groups
+  text = '''
+    input float: a(16, *)   # comment
+    iterate: 3
+    output float: b(0, 0) = a(0, 0) + a(1, 1)
+    unroll factor: 4
+    kernel: demo
+    burst width: 256
+  '''
+  st = frontend.loads(text)
+  assert (st.app_name, st.iterate, st.unroll_factor, st.burst_width) == \
+      ('demo', 3, 4, 256)
+  assert st.radius() == ((0, 0), (1, 1))
+  assert st.valid_margins()[-1] == ((0, 0), (3, 3))
+
+
+@pytest.mark.parametrize('text,rendered', [
+    ('a(0) + b(1) * 2', '(a(0) + (b(1) * 2))'),
+    ('- - a(0)', 'a(0)'),
+    ('-a(0)', '-a(0)'),
+    ('!!a(0)', 'a(0)'),
+    ('(a(0))', 'a(0)'),
+    ('65535 - (a(0) * a(0) + b(0) * b(0))', '(65535 - (a(0) * a(0)) + (b(0) * b(0)))'),
+    ('float(a(0)) / 3', '(float(a(0)) / 3)'),
+    ('sqrt(a(0) + 1.0f)', 'sqrt((a(0) + 1.0f))'),
+    # the wrapper's strip-all-then-add-one rule drops the && chain's own parens
+    ('a(0) < b(0) && a(0) != 3 || x', '((a(0) < b(0)) && (a(0) != 3) || x)'),
+    ('a(0) & 0xFFu | 1 ^ 2', '((a(0) & 0xFFu) | (1 ^ 2))'),
+])
+def test_expression_text(text, rendered):
+  assert ex.soda_text(frontend.parse_expression(text)) == rendered
+
+
+def test_cast_c_text():
+  node = frontend.parse_expression('uint16(a(0, 0) + 1) * 2')
+  text = ex.c_text(node, lambda ld: 'A', c_type)
+  assert text == '(static_cast<uint16_t >(A + 1) * 2)'
+
+
+def test_let_types():
+  st = frontend.loads('''
+    kernel: k
+    burst width: 64
+    unroll factor: 1
+    iterate: 1
+    input uint16: a(8, *)
+    output uint16: float s = a(0, 0) + a(1, 0) t = s * 0.5f b(0, 0) = t + a(0, 1)
+  ''')
+  stage = st.stages['b']
+  assert [(n, t) for n, t, _ in stage.lets] == [('s', 'float'), ('t', 'float')]
+  assert st.radius() == ((0, 0), (1, 1))
+
+
+@pytest.mark.parametrize('text', [
+    'kernel: k\nburst width: 1\nunroll factor: 1\ninput float: a(4,*)\noutput float: b(0,0) = a(0,0)',  # no iterate
+    'kernel: k\nkernel: j\nburst width: 1\nunroll factor: 1\niterate: 1\ninput float: a(4,*)\noutput float: b(0,0) = a(0,0)',
+    'kernel: k\nburst width: 1\nunroll factor: 1\niterate: 1\ninput float: a(4,*)',  # no output
+    'kernel: k\nburst width: 1\nunroll factor: 1\niterate: 1\ninput float: a(4,*)\noutput float: b(0,0) = a(0,0) +',
+    'kernel: k\nburst width: 1\nunroll factor: 1\niterate: 1\ninput float: a(4,*)\noutput float: b(0,0) = a(0,x)',
+    'kernel: k\nburst width: 1\nunroll factor: 1\niterate: 1\ninput float: a(4,*)\noutput float: b(0,0) = a(0,0)\ninput float: c',
+    'kernel: k\nburst width: 1\nunroll factor: 1\niterate: 1\ninput flat: a(4,*)\noutput float: b(0,0) = a(0,0)',
+    'kernel: k\nburst width: 1\nunroll factor: 1\niterate: 1\ninput float: a(4,*)\noutput float: b(0,0) = a(0,0) $ 2',
+])
+def test_syntax_errors(text):
+  with pytest.raises(SodaSyntaxError):
+    frontend.loads(text)
+
+
+def test_semantic_errors():
+  base = 'kernel: k\nburst width: 1\nunroll factor: 1\n'
+  with pytest.raises(SemanticError, match='cannot iterate 0 times'):
+    frontend.loads(base + 'iterate: 0\ninput float: a(4,*)\noutput float: b(0,0) = a(0,0)')
+  with pytest.raises(SemanticError, match='number of input tensors'):
+    frontend.loads(base + 'iterate: 2\ninput float: a(4,*)\ninput float: c(4,*)\n'
+                   'output float: b(0,0) = a(0,0) + c(0,0)')
+  with pytest.raises(SemanticError, match='same type'):
+    frontend.loads(base + 'iterate: 2\ninput float: a(4,*)\noutput uint16: b(0,0) = a(0,0)')
+  with pytest.raises(SemanticError, match="doesn't match previous"):
+    frontend.loads(base + 'iterate: 1\ninput float: a(4,*)\ninput float: c\n'
+                   'output float: b(0,0) = a(0,0) + c(0,0)')
+  with pytest.raises(SemanticError, match='undefined tensor'):
+    frontend.loads(base + 'iterate: 1\ninput float: a(4,*)\noutput float: b(0,0) = z(0,0)')
+
+
+def test_overrides_like_sodac():
+  st = frontend.load(os.path.join(SAMPLES, 'jacobi2d.soda'), iterate=7,
+                     tile_size=[2000], unroll_factor=8, burst_width=256)
+  assert (st.iterate, st.tile_size, st.unroll_factor, st.burst_width) == \
+      (7, (2000, 0), 8, 256)
+  assert st.valid_margins()[-1] == ((7, 7), (7, 7))
+  # tile size 0 keeps the DSL's value on that dimension (sodac:94-102)
+  st = frontend.load(os.path.join(SAMPLES, 'jacobi3d.soda'), tile_size=[0, 64])
+  assert st.tile_size == (32, 64, 0)
