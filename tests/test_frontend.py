@@ -109,7 +109,7 @@ def test_readme_example_any_key_order():
     ('sqrt(a(0) + 1.0f)', 'sqrt((a(0) + 1.0f))'),
     # the wrapper's strip-all-then-add-one rule drops the && chain's own parens
     ('a(0) < b(0) && a(0) != 3 || x', '((a(0) < b(0)) && (a(0) != 3) || x)'),
-    ('a(0) & 0xFFu | 1 ^ 2', '((a(0) & 0xFFu) | (1 ^ 2))'),
+    ('a(0) & 0xFFu | 1 ^ 2', '(a(0) & 0xFFu) | (1 ^ 2)'),
 ])
 def test_expression_text(text, rendered):
   assert ex.soda_text(frontend.parse_expression(text)) == rendered
