@@ -1,0 +1,241 @@
+/* soda_hip.h -- C ABI of libsoda_hip.so, the MI355X (gfx950) run-time of the
+ * SODA HIP back end.
+ *
+ * The reference compiler (UCLA-VAST/soda-compiler) has no run-time library: its
+ * host printer emits a whole OpenCL host program per stencil
+ * (src/soda/codegen/xilinx/host.py).  The pieces of that generated program that
+ * sit on the stencil hot path are what this library replaces; each entry point
+ * cites the generated function (by the printer lines that emit it) it stands in
+ * for.  `sodac --hip-host` emits a thin shim that only fills in the descriptors
+ * below and calls these functions (INTEGRATION.md shows the shim).
+ *
+ * Conventions
+ *   - plain C, no HIP/torch types: device pointers are `void*`, a stream is a
+ *     `void*` holding a hipStream_t (NULL = the null stream);
+ *   - every function returns 0 on success or a negative code; nothing calls
+ *     exit() (the generated reference host does, e.g. host.py:399-404).  Codes
+ *     reuse the reference's Halide numbering (host.py:118-133) where one applies;
+ *   - soda_hip_last_error() gives the detail text of the calling thread's most
+ *     recent failure;
+ *   - dimension 0 is the fastest-varying one (stride 1), the LAST dimension is
+ *     the streamed / outermost one (host.py:1014-1017).
+ */
+#ifndef SODA_HIP_H_
+#define SODA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SODA_HIP_ABI_VERSION 1
+#define SODA_HIP_MAX_DIMS 4
+#define SODA_HIP_MAX_TENSORS 16 /* inputs + stages of one program */
+#define SODA_HIP_MAX_IO 8
+#define SODA_HIP_MAX_WINDOWS 64
+#define SODA_HIP_MAX_KERNELS 32
+
+/* ---- return codes (reference host.py:118-133 numbering) ------------------ */
+enum {
+  SODA_HIP_OK = 0,
+  SODA_HIP_ERR_GENERIC = -1,
+  SODA_HIP_ERR_BAD_ELEM_SIZE = -3,       /* halide_error_code_bad_elem_size */
+  SODA_HIP_ERR_OUT_OF_BOUNDS = -4,       /* ..._access_out_of_bounds */
+  SODA_HIP_ERR_EXTENTS_TOO_LARGE = -6,   /* ..._buffer_extents_too_large */
+  SODA_HIP_ERR_CONSTRAINT = -8,          /* ..._constraint_violated */
+  SODA_HIP_ERR_OUT_OF_MEMORY = -11,      /* ..._out_of_memory */
+  SODA_HIP_ERR_NULL_ARGUMENT = -12,      /* ..._buffer_argument_is_null */
+  SODA_HIP_ERR_COPY_TO_HOST = -14,       /* ..._copy_to_host_failed */
+  SODA_HIP_ERR_COPY_TO_DEVICE = -15,     /* ..._copy_to_device_failed */
+  SODA_HIP_ERR_DEVICE_MALLOC = -16,      /* ..._device_malloc_failed */
+  SODA_HIP_ERR_DEVICE_SYNC = -17,        /* ..._device_sync_failed */
+  SODA_HIP_ERR_DEVICE_FREE = -18,        /* ..._device_free_failed */
+  SODA_HIP_ERR_NO_DEVICE = -19,          /* ..._no_device_interface */
+  SODA_HIP_ERR_INTERNAL = -22,           /* ..._internal_error */
+  SODA_HIP_ERR_DEVICE_RUN = -23,         /* ..._device_run_failed */
+  /* no Halide counterpart */
+  SODA_HIP_ERR_COMPILE = -100,           /* hiprtc rejected the kernel text */
+  SODA_HIP_ERR_MODULE = -101,            /* code object unreadable / wrong arch */
+  SODA_HIP_ERR_NO_KERNEL = -102,         /* kernel name not in the module */
+  SODA_HIP_ERR_MISMATCH = -103           /* blob built for another program */
+};
+
+const char* soda_hip_error_name(int code);
+const char* soda_hip_last_error(void);
+int soda_hip_abi_version(void);
+
+/* ---- device ---------------------------------------------------------------
+ * Replaces the platform/device/context discovery of the generated host
+ * (host.py:412-560). */
+int soda_hip_device_count(int* count);
+int soda_hip_set_device(int ordinal);
+/* name: gcnArchName such as "gfx950:sramecc+:xnack-"; cu: compute units */
+int soda_hip_device_info(int ordinal, char* name, size_t name_cap, int* cu,
+                         uint64_t* total_mem_bytes);
+int soda_hip_malloc(void** dev, size_t bytes);           /* host.py:574-594 */
+int soda_hip_free(void* dev);                            /* host.py:913-924 */
+int soda_hip_memset(void* dev, int value, size_t bytes, void* stream);
+int soda_hip_memcpy_h2d(void* dev, const void* host, size_t bytes, void* stream);
+int soda_hip_memcpy_d2h(void* host, const void* dev, size_t bytes, void* stream);
+int soda_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+int soda_hip_stream_synchronize(void* stream);           /* host.py:781-790 */
+
+/* ---- kernel blob ------------------------------------------------------------
+ * The `xclbin` argument of the generated entry points (host.py:931, :992)
+ * becomes a "blob": either a gfx950 code object built ahead of time from the
+ * text `sodac --hip-kernel` prints, or that text itself, compiled here with
+ * hiprtc (replaces load_xclbin2_to_memory + clCreateProgramWithBinary,
+ * host.py:49-97, :520-560). */
+typedef struct soda_hip_module soda_hip_module;
+
+int soda_hip_module_load_file(const char* code_object_path,
+                              soda_hip_module** module);
+int soda_hip_module_load_data(const void* image, size_t bytes,
+                              soda_hip_module** module);
+/* arch NULL = the current device's; options are extra hiprtc flags */
+int soda_hip_module_compile(const char* source, const char* arch,
+                            const char* const* options, int n_options,
+                            soda_hip_module** module);
+/* the compiled code object, e.g. to cache it on disk */
+int soda_hip_module_image(const soda_hip_module* module, const void** image,
+                          size_t* bytes);
+/* JSON text the kernel printer stored in the blob (`soda_hip_meta` symbol):
+ * program hash, spec and the kernel table.  Copies up to cap-1 bytes. */
+int soda_hip_module_meta(const soda_hip_module* module, char* buf, size_t cap,
+                         size_t* length);
+int soda_hip_module_unload(soda_hip_module* module);
+
+/* ---- program + kernel descriptors ----------------------------------------
+ * What the reference bakes into the generated host as literals: tensor types
+ * (host.py:254-255), the stencil window (STENCIL_DIM_n, host.py:1183-1197).
+ * Tensors are numbered inputs first, then stages in execution order. */
+typedef struct soda_hip_window {
+  int32_t stage;   /* tensor index of the reading stage */
+  int32_t parent;  /* tensor index of the tensor read */
+  int32_t lo[SODA_HIP_MAX_DIMS];  /* hull of (load index - store index) */
+  int32_t hi[SODA_HIP_MAX_DIMS];
+} soda_hip_window;
+
+typedef struct soda_hip_program {
+  int32_t dim;
+  int32_t n_inputs;
+  int32_t n_stages;
+  int32_t n_outputs;
+  int32_t elem_size[SODA_HIP_MAX_TENSORS];
+  int32_t output_tensor[SODA_HIP_MAX_IO]; /* tensor index of output j; it feeds
+                                             input j when iterating */
+  int32_t n_windows;
+  soda_hip_window window[SODA_HIP_MAX_WINDOWS];
+} soda_hip_program;
+
+enum {
+  SODA_HIP_KERNEL_STAGE = 0, /* one stage of one iteration, result to HBM */
+  SODA_HIP_KERNEL_FUSED = 1  /* `depth` whole iterations, all stages fused */
+};
+
+typedef struct soda_hip_kernel {
+  char name[96];
+  int32_t kind;
+  int32_t depth;    /* FUSED: iterations advanced per launch */
+  int32_t stage;    /* STAGE: tensor index produced */
+  int32_t block[3]; /* workgroup shape */
+  int32_t tile[SODA_HIP_MAX_DIMS]; /* output cells one workgroup produces */
+  int32_t reserved[4];
+} soda_hip_kernel;
+
+/* By-value argument of every generated kernel. */
+typedef struct soda_hip_args {
+  void* tensor[SODA_HIP_MAX_TENSORS]; /* by tensor index; unused = NULL */
+  int64_t dims[SODA_HIP_MAX_DIMS];    /* array extents */
+  int64_t box_lo[SODA_HIP_MAX_DIMS];  /* cells to produce: [box_lo, box_hi) */
+  int64_t box_hi[SODA_HIP_MAX_DIMS];
+} soda_hip_args;
+
+/* ---- plan -------------------------------------------------------------------
+ * A program bound to a blob.  Owns its scratch device memory (ping-pong partner
+ * of the outputs, stage intermediates), sized on first use, freed on destroy. */
+typedef struct soda_hip_plan soda_hip_plan;
+
+int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* program,
+                         const soda_hip_kernel* kernels, int n_kernels,
+                         soda_hip_plan** plan);
+int soda_hip_plan_destroy(soda_hip_plan* plan);
+
+/* margins after `iterations` iterations: outputs are defined on
+ * [lo[d], dims[d] - hi[d]) (reference core.py:794-835, host.py:1082-1091) */
+int soda_hip_plan_margins(const soda_hip_plan* plan, int iterations,
+                          int32_t lo[SODA_HIP_MAX_DIMS],
+                          int32_t hi[SODA_HIP_MAX_DIMS]);
+
+typedef struct soda_hip_timing {
+  double kernel_us;     /* device time of the timed sweep loop (hipEvents) */
+  int32_t launches;     /* kernel launches in one sweep loop */
+  int32_t max_depth;    /* deepest temporal block used */
+  double dominant_us;   /* summed device time of the dominant kernel ... */
+  int32_t dominant_launches; /* ... over this many launches */
+  char dominant_name[96];
+} soda_hip_timing;
+
+/* The device sweep: `iterate` applications of the program on device arrays.
+ *   in[j]   level-0 arrays, never written
+ *   out[j]  receive level `iterate`; cells outside the valid box are
+ *           unspecified (the reference leaves them unspecified too)
+ *   valid_lo/valid_hi  NULL, or per-dimension margins of the region of `in`
+ *           that holds defined data: [valid_lo[d], dims[d] - valid_hi[d]).
+ *           NULL means the whole array (a fresh run).  A caller that resumes
+ *           after t iterations passes the margins of iteration t; a caller that
+ *           owns a slab of a larger grid passes 0 on the sides whose ghost rows
+ *           a neighbour just refreshed.
+ * The outputs are then defined on the box shrunk by soda_hip_plan_margins(
+ * iterate).  Stands in for the clEnqueueTask of the generated host
+ * (host.py:775-790) plus the FPGA kernel itself (hls_kernel.py:12-103).
+ * Asynchronous on `stream`. */
+int soda_hip_sweep(soda_hip_plan* plan, void* const* in, void* const* out,
+                   const int64_t dims[SODA_HIP_MAX_DIMS], int iterate,
+                   const int32_t* valid_lo, const int32_t* valid_hi,
+                   void* stream);
+
+/* Same, bracketed by hipEvents on `stream`: `warmup` untimed runs, then
+ * `repeats` timed ones (reference protocol host.py:775-796: one warm-up, one
+ * timed run).  Synchronises the stream. */
+int soda_hip_sweep_timed(soda_hip_plan* plan, void* const* in, void* const* out,
+                         const int64_t dims[SODA_HIP_MAX_DIMS], int iterate,
+                         int warmup, int repeats, void* stream,
+                         soda_hip_timing* timing);
+
+/* Restricts fused kernels to depth <= max_depth (0 = no limit); for tests and
+ * tuning. */
+int soda_hip_plan_set_max_depth(soda_hip_plan* plan, int max_depth);
+
+/* ---- host-buffer entry (the generated `<app>`) ------------------------------
+ * Legacy Halide buffer_t, bit-compatible with the struct the reference's
+ * header printer emits (header.py:36-48). */
+typedef struct soda_hip_buffer_t {
+  uint64_t dev;
+  uint8_t* host;
+  int32_t extent[4];
+  int32_t stride[4];
+  int32_t min[4];
+  int32_t elem_size;
+  uint8_t host_dirty;
+  uint8_t dev_dirty;
+  uint8_t _padding[10 - sizeof(void*)];
+} soda_hip_buffer_t;
+
+/* `int <app>(buffer_t* in..., buffer_t* out..., const char* xclbin)`
+ * (host.py:931-945 -> :186-929): checks element sizes, bounds-query mode when a
+ * buffer has host == NULL && dev == 0 (host.py:204-252), device buffers created
+ * and freed inside the call, one warm-up then one timed run, prints
+ * "Kernel execution time: %lf us" / "Kernel throughput: %lf pixel/ns" to stdout
+ * (host.py:796-800), writes only the valid interior of each output back
+ * (host.py:838-899).  timing may be NULL. */
+int soda_hip_run_buffers(soda_hip_plan* plan, soda_hip_buffer_t* const* inputs,
+                         soda_hip_buffer_t* const* outputs, int iterate,
+                         soda_hip_timing* timing);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SODA_HIP_H_ */

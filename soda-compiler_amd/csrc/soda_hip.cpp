@@ -1,0 +1,879 @@
+// libsoda_hip.so -- run-time of the SODA HIP back end for MI355X (gfx950).
+//
+// Thin and stateless per call apart from the handles it hands out: a module
+// (one code object), a plan (program + kernels + scratch memory).  The stencil
+// arithmetic lives in the generated kernels (soda_hip/codegen/kernel_*.py); this
+// file decides which kernel runs on which box with which buffers, launches it on
+// the caller's stream and times it with hipEvents.
+//
+// Reference counterparts are cited per function in include/soda_hip.h.
+#include "soda_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(code, call)                                                   \
+  do {                                                                        \
+    hipError_t e_ = (call);                                                   \
+    if (e_ != hipSuccess)                                                     \
+      return fail((code), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                        \
+  } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+struct Box {
+  int32_t lo[SODA_HIP_MAX_DIMS];  // <= 0
+  int32_t hi[SODA_HIP_MAX_DIMS];  // >= 0
+  bool set;
+};
+
+}  // namespace
+
+struct soda_hip_module {
+  hipModule_t mod = nullptr;
+  std::vector<char> image;
+  std::string meta;
+};
+
+struct soda_hip_plan {
+  soda_hip_module* module = nullptr;
+  soda_hip_program prog{};
+  std::vector<soda_hip_kernel> kernels;
+  std::vector<hipFunction_t> funcs;
+  int max_depth = 0;
+  // scratch: [0, n_outputs) ping-pong partner of the outputs,
+  // then one per non-output stage (only used by per-stage kernels)
+  std::vector<void*> scratch;
+  std::vector<size_t> scratch_bytes;
+  // composed boxes per iteration per stage, grown on demand
+  std::vector<std::vector<Box>> boxes;
+  std::vector<Box> feed;
+};
+
+namespace {
+
+int n_tensors(const soda_hip_program& p) { return p.n_inputs + p.n_stages; }
+
+bool is_output_tensor(const soda_hip_program& p, int t) {
+  for (int j = 0; j < p.n_outputs; ++j)
+    if (p.output_tensor[j] == t) return true;
+  return false;
+}
+
+// Composed read windows back to the original inputs, one iteration at a time
+// (reference core.py:794-835 on bounding boxes; output j feeds input j,
+// core.py:342-360).
+void grow_boxes(soda_hip_plan* plan, int iterations) {
+  const soda_hip_program& p = plan->prog;
+  const int nt = n_tensors(p);
+  if (plan->boxes.empty()) {
+    plan->feed.assign(p.n_inputs, Box{});
+    for (auto& b : plan->feed) b.set = true;
+  }
+  while ((int)plan->boxes.size() < iterations) {
+    std::vector<Box> cur(nt, Box{});
+    for (int i = 0; i < p.n_inputs; ++i) cur[i] = plan->feed[i];
+    for (int s = 0; s < p.n_stages; ++s) {
+      const int t = p.n_inputs + s;
+      Box acc{};
+      for (int w = 0; w < p.n_windows; ++w) {
+        const soda_hip_window& win = p.window[w];
+        if (win.stage != t) continue;
+        const Box& par = cur[win.parent];
+        for (int d = 0; d < p.dim; ++d) {
+          const int32_t lo = par.lo[d] + win.lo[d], hi = par.hi[d] + win.hi[d];
+          acc.lo[d] = acc.set ? std::min(acc.lo[d], lo) : lo;
+          acc.hi[d] = acc.set ? std::max(acc.hi[d], hi) : hi;
+        }
+        acc.set = true;
+      }
+      cur[t] = acc;
+    }
+    if (p.n_inputs == p.n_outputs)
+      for (int j = 0; j < p.n_inputs; ++j) plan->feed[j] = cur[p.output_tensor[j]];
+    plan->boxes.push_back(cur);
+  }
+}
+
+// hull over the outputs after `iterations` iterations, as positive margins
+void output_margins(soda_hip_plan* plan, int iterations, int32_t* lo, int32_t* hi) {
+  const soda_hip_program& p = plan->prog;
+  for (int d = 0; d < SODA_HIP_MAX_DIMS; ++d) lo[d] = hi[d] = 0;
+  if (iterations <= 0) return;
+  grow_boxes(plan, iterations);
+  const std::vector<Box>& b = plan->boxes[iterations - 1];
+  for (int j = 0; j < p.n_outputs; ++j) {
+    const Box& o = b[p.output_tensor[j]];
+    for (int d = 0; d < p.dim; ++d) {
+      lo[d] = std::max(lo[d], -o.lo[d]);
+      hi[d] = std::max(hi[d], o.hi[d]);
+    }
+  }
+}
+
+int ensure_scratch(soda_hip_plan* plan, const int64_t* dims, bool need_locals,
+                   bool need_pingpong) {
+  const soda_hip_program& p = plan->prog;
+  size_t cells = 1;
+  for (int d = 0; d < p.dim; ++d) cells *= (size_t)dims[d];
+  const int n_slots = p.n_outputs + p.n_stages;
+  if ((int)plan->scratch.size() != n_slots) {
+    plan->scratch.assign(n_slots, nullptr);
+    plan->scratch_bytes.assign(n_slots, 0);
+  }
+  auto want = [&](int slot, size_t bytes) -> int {
+    if (plan->scratch_bytes[slot] >= bytes) return 0;
+    if (plan->scratch[slot]) {
+      HIP_TRY(SODA_HIP_ERR_DEVICE_FREE, hipFree(plan->scratch[slot]));
+      plan->scratch[slot] = nullptr;
+      plan->scratch_bytes[slot] = 0;
+    }
+    HIP_TRY(SODA_HIP_ERR_DEVICE_MALLOC, hipMalloc(&plan->scratch[slot], bytes));
+    // unspecified cells must at least be readable, finite-ish garbage: zero
+    HIP_TRY(SODA_HIP_ERR_DEVICE_RUN, hipMemset(plan->scratch[slot], 0, bytes));
+    plan->scratch_bytes[slot] = bytes;
+    return 0;
+  };
+  if (need_pingpong)
+    for (int j = 0; j < p.n_outputs; ++j) {
+      int rc = want(j, cells * p.elem_size[p.output_tensor[j]]);
+      if (rc) return rc;
+    }
+  if (need_locals)
+    for (int s = 0; s < p.n_stages; ++s) {
+      const int t = p.n_inputs + s;
+      if (is_output_tensor(p, t)) continue;
+      int rc = want(p.n_outputs + s, cells * p.elem_size[t]);
+      if (rc) return rc;
+    }
+  return 0;
+}
+
+struct Launch {
+  int kernel;
+  soda_hip_args args;
+  unsigned grid[3];
+};
+
+int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
+                Launch* out, bool* empty) {
+  const soda_hip_kernel& desc = plan->kernels[k];
+  const int dim = plan->prog.dim;
+  out->kernel = k;
+  out->args = args;
+  *empty = false;
+  for (int d = 0; d < 3; ++d) out->grid[d] = 1;
+  if (dim > 3) return fail(SODA_HIP_ERR_INTERNAL, "4-D launches are not implemented");
+  for (int d = 0; d < dim; ++d) {
+    const int64_t extent = args.box_hi[d] - args.box_lo[d];
+    if (extent <= 0) { *empty = true; return 0; }
+    if (desc.tile[d] <= 0)
+      return fail(SODA_HIP_ERR_INTERNAL, "kernel %s has tile[%d]=%d", desc.name, d,
+                  desc.tile[d]);
+    const int64_t g = (extent + desc.tile[d] - 1) / desc.tile[d];
+    if (g > (d == 0 ? 2147483647LL : 65535LL))
+      return fail(SODA_HIP_ERR_EXTENTS_TOO_LARGE,
+                  "grid dimension %d of kernel %s would be %lld", d, desc.name,
+                  (long long)g);
+    out->grid[d] = (unsigned)g;
+  }
+  return 0;
+}
+
+int check_box_inside(const soda_hip_plan* plan, const soda_hip_args& a,
+                     const int32_t* reach_lo, const int32_t* reach_hi) {
+  // every cell a launch may read must be inside the array: the kernels rely on it
+  for (int d = 0; d < plan->prog.dim; ++d) {
+    if (a.box_hi[d] <= a.box_lo[d]) continue;
+    if (a.box_lo[d] - reach_lo[d] < 0 || a.box_hi[d] + reach_hi[d] > a.dims[d])
+      return fail(SODA_HIP_ERR_OUT_OF_BOUNDS,
+                  "launch would read [%lld, %lld) of dimension %d, extent %lld",
+                  (long long)(a.box_lo[d] - reach_lo[d]),
+                  (long long)(a.box_hi[d] + reach_hi[d]), d, (long long)a.dims[d]);
+  }
+  return 0;
+}
+
+// Builds the launch list of one sweep.
+int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
+                   const int64_t* dims, int iterate, const int32_t* valid_lo,
+                   const int32_t* valid_hi, std::vector<Launch>* list,
+                   int* max_depth_used) {
+  const soda_hip_program& p = plan->prog;
+  if (iterate < 1) return fail(SODA_HIP_ERR_CONSTRAINT, "iterate must be >= 1");
+  if (iterate > 1 && p.n_inputs != p.n_outputs)
+    return fail(SODA_HIP_ERR_CONSTRAINT,
+                "iterate > 1 needs as many outputs as inputs (%d vs %d)",
+                p.n_inputs, p.n_outputs);
+  for (int j = 0; j < p.n_inputs; ++j)
+    if (!in[j]) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "input %d is NULL", j);
+  for (int j = 0; j < p.n_outputs; ++j)
+    if (!out[j]) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "output %d is NULL", j);
+  int32_t vlo[SODA_HIP_MAX_DIMS] = {0, 0, 0, 0}, vhi[SODA_HIP_MAX_DIMS] = {0, 0, 0, 0};
+  for (int d = 0; d < p.dim; ++d) {
+    if (valid_lo) vlo[d] = valid_lo[d];
+    if (valid_hi) vhi[d] = valid_hi[d];
+    if (dims[d] <= 0) return fail(SODA_HIP_ERR_CONSTRAINT, "dims[%d] = %lld", d,
+                                  (long long)dims[d]);
+  }
+  grow_boxes(plan, iterate);
+  list->clear();
+  *max_depth_used = 0;
+
+  // fused kernels available?  (single hull box => single-output programs, or
+  // outputs that share a window; the printer only emits them when that holds)
+  std::vector<int> fused;  // kernel indices sorted by depth descending
+  for (size_t k = 0; k < plan->kernels.size(); ++k)
+    if (plan->kernels[k].kind == SODA_HIP_KERNEL_FUSED &&
+        (plan->max_depth <= 0 || plan->kernels[k].depth <= plan->max_depth))
+      fused.push_back((int)k);
+  std::sort(fused.begin(), fused.end(), [&](int a, int b) {
+    return plan->kernels[a].depth > plan->kernels[b].depth;
+  });
+  bool fused_ok = !fused.empty() && plan->kernels[fused.back()].depth == 1;
+  if (plan->max_depth < 0) fused_ok = false;  // force per-stage kernels
+
+  if (fused_ok) {
+    // greedy split of `iterate` into available depths
+    std::vector<int> seq;
+    for (int left = iterate; left > 0;) {
+      int pick = -1;
+      for (int k : fused)
+        if (plan->kernels[k].depth <= left) { pick = k; break; }
+      if (pick < 0) return fail(SODA_HIP_ERR_INTERNAL, "no fused kernel of depth 1");
+      seq.push_back(pick);
+      left -= plan->kernels[pick].depth;
+    }
+    const int m = (int)seq.size();
+    if (m > 1) {
+      int rc = ensure_scratch(plan, dims, false, true);
+      if (rc) return rc;
+    }
+    int done = 0;
+    std::vector<void*> src(in, in + p.n_inputs);
+    for (int i = 0; i < m; ++i) {
+      const soda_hip_kernel& desc = plan->kernels[seq[i]];
+      // destinations alternate so that the last one is `out`
+      const bool to_out = ((m - 1 - i) % 2) == 0;
+      soda_hip_args a;
+      memset(&a, 0, sizeof a);
+      for (int j = 0; j < p.n_inputs; ++j) a.tensor[j] = src[j];
+      std::vector<void*> dst(p.n_outputs);
+      for (int j = 0; j < p.n_outputs; ++j) {
+        dst[j] = to_out ? out[j] : plan->scratch[j];
+        a.tensor[p.output_tensor[j]] = dst[j];
+      }
+      int32_t mlo[SODA_HIP_MAX_DIMS], mhi[SODA_HIP_MAX_DIMS];
+      int32_t plo[SODA_HIP_MAX_DIMS], phi[SODA_HIP_MAX_DIMS];
+      output_margins(plan, done, plo, phi);
+      output_margins(plan, done + desc.depth, mlo, mhi);
+      int32_t reach_lo[SODA_HIP_MAX_DIMS], reach_hi[SODA_HIP_MAX_DIMS];
+      for (int d = 0; d < SODA_HIP_MAX_DIMS; ++d) {
+        a.dims[d] = d < p.dim ? dims[d] : 1;
+        a.box_lo[d] = d < p.dim ? vlo[d] + mlo[d] : 0;
+        a.box_hi[d] = d < p.dim ? dims[d] - vhi[d] - mhi[d] : 1;
+        reach_lo[d] = mlo[d] - plo[d];
+        reach_hi[d] = mhi[d] - phi[d];
+      }
+      int rc = check_box_inside(plan, a, reach_lo, reach_hi);
+      if (rc) return rc;
+      Launch l;
+      bool empty;
+      rc = make_launch(plan, seq[i], a, &l, &empty);
+      if (rc) return rc;
+      if (!empty) list->push_back(l);
+      *max_depth_used = std::max(*max_depth_used, (int)desc.depth);
+      done += desc.depth;
+      if (p.n_inputs == p.n_outputs) src = dst;
+    }
+    return 0;
+  }
+
+  // per-stage kernels: one launch per stage per iteration, intermediates in HBM
+  std::vector<int> stage_kernel(p.n_stages, -1);
+  for (size_t k = 0; k < plan->kernels.size(); ++k)
+    if (plan->kernels[k].kind == SODA_HIP_KERNEL_STAGE) {
+      const int s = plan->kernels[k].stage - p.n_inputs;
+      if (s >= 0 && s < p.n_stages) stage_kernel[s] = (int)k;
+    }
+  for (int s = 0; s < p.n_stages; ++s)
+    if (stage_kernel[s] < 0)
+      return fail(SODA_HIP_ERR_NO_KERNEL, "blob has no kernel for stage %d", s);
+  {
+    int rc = ensure_scratch(plan, dims, true, iterate > 1);
+    if (rc) return rc;
+  }
+  std::vector<void*> src(in, in + p.n_inputs);
+  for (int it = 0; it < iterate; ++it) {
+    const bool to_out = ((iterate - 1 - it) % 2) == 0;
+    soda_hip_args a;
+    memset(&a, 0, sizeof a);
+    for (int j = 0; j < p.n_inputs; ++j) a.tensor[j] = src[j];
+    std::vector<void*> dst(p.n_outputs);
+    for (int s = 0; s < p.n_stages; ++s)
+      a.tensor[p.n_inputs + s] = plan->scratch[p.n_outputs + s];
+    for (int j = 0; j < p.n_outputs; ++j) {
+      dst[j] = to_out ? out[j] : plan->scratch[j];
+      a.tensor[p.output_tensor[j]] = dst[j];
+    }
+    for (int d = 0; d < SODA_HIP_MAX_DIMS; ++d) a.dims[d] = d < p.dim ? dims[d] : 1;
+    for (int s = 0; s < p.n_stages; ++s) {
+      const Box& b = plan->boxes[it][p.n_inputs + s];
+      for (int d = 0; d < SODA_HIP_MAX_DIMS; ++d) {
+        a.box_lo[d] = d < p.dim ? vlo[d] - b.lo[d] : 0;
+        a.box_hi[d] = d < p.dim ? dims[d] - vhi[d] - b.hi[d] : 1;
+      }
+      Launch l;
+      bool empty;
+      int rc = make_launch(plan, stage_kernel[s], a, &l, &empty);
+      if (rc) return rc;
+      if (!empty) list->push_back(l);
+    }
+    if (p.n_inputs == p.n_outputs) src = dst;
+  }
+  *max_depth_used = 1;
+  return 0;
+}
+
+int launch_one(const soda_hip_plan* plan, const Launch& l, hipStream_t stream) {
+  const soda_hip_kernel& desc = plan->kernels[l.kernel];
+  soda_hip_args args = l.args;
+  size_t size = sizeof args;
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args,
+                    HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  HIP_TRY(SODA_HIP_ERR_DEVICE_RUN,
+          hipModuleLaunchKernel(plan->funcs[l.kernel], l.grid[0], l.grid[1],
+                                l.grid[2], desc.block[0], desc.block[1],
+                                desc.block[2], 0, stream, nullptr, config));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* soda_hip_error_name(int code) {
+  switch (code) {
+    case SODA_HIP_OK: return "ok";
+    case SODA_HIP_ERR_GENERIC: return "generic_error";
+    case SODA_HIP_ERR_BAD_ELEM_SIZE: return "bad_elem_size";
+    case SODA_HIP_ERR_OUT_OF_BOUNDS: return "access_out_of_bounds";
+    case SODA_HIP_ERR_EXTENTS_TOO_LARGE: return "buffer_extents_too_large";
+    case SODA_HIP_ERR_CONSTRAINT: return "constraint_violated";
+    case SODA_HIP_ERR_OUT_OF_MEMORY: return "out_of_memory";
+    case SODA_HIP_ERR_NULL_ARGUMENT: return "buffer_argument_is_null";
+    case SODA_HIP_ERR_COPY_TO_HOST: return "copy_to_host_failed";
+    case SODA_HIP_ERR_COPY_TO_DEVICE: return "copy_to_device_failed";
+    case SODA_HIP_ERR_DEVICE_MALLOC: return "device_malloc_failed";
+    case SODA_HIP_ERR_DEVICE_SYNC: return "device_sync_failed";
+    case SODA_HIP_ERR_DEVICE_FREE: return "device_free_failed";
+    case SODA_HIP_ERR_NO_DEVICE: return "no_device_interface";
+    case SODA_HIP_ERR_INTERNAL: return "internal_error";
+    case SODA_HIP_ERR_DEVICE_RUN: return "device_run_failed";
+    case SODA_HIP_ERR_COMPILE: return "kernel_compile_failed";
+    case SODA_HIP_ERR_MODULE: return "bad_code_object";
+    case SODA_HIP_ERR_NO_KERNEL: return "kernel_not_found";
+    case SODA_HIP_ERR_MISMATCH: return "blob_program_mismatch";
+    default: return "unknown_error";
+  }
+}
+
+const char* soda_hip_last_error(void) { return g_last_error.c_str(); }
+int soda_hip_abi_version(void) { return SODA_HIP_ABI_VERSION; }
+
+int soda_hip_device_count(int* count) {
+  if (!count) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(SODA_HIP_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return 0;
+}
+
+int soda_hip_set_device(int ordinal) {
+  HIP_TRY(SODA_HIP_ERR_NO_DEVICE, hipSetDevice(ordinal));
+  return 0;
+}
+
+int soda_hip_device_info(int ordinal, char* name, size_t name_cap, int* cu,
+                         uint64_t* total_mem_bytes) {
+  hipDeviceProp_t prop;
+  HIP_TRY(SODA_HIP_ERR_NO_DEVICE, hipGetDeviceProperties(&prop, ordinal));
+  if (name && name_cap) snprintf(name, name_cap, "%s", prop.gcnArchName);
+  if (cu) *cu = prop.multiProcessorCount;
+  if (total_mem_bytes) *total_mem_bytes = prop.totalGlobalMem;
+  return 0;
+}
+
+int soda_hip_malloc(void** dev, size_t bytes) {
+  if (!dev) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "dev is NULL");
+  HIP_TRY(SODA_HIP_ERR_DEVICE_MALLOC, hipMalloc(dev, bytes ? bytes : 1));
+  return 0;
+}
+
+int soda_hip_free(void* dev) {
+  if (dev) HIP_TRY(SODA_HIP_ERR_DEVICE_FREE, hipFree(dev));
+  return 0;
+}
+
+int soda_hip_memset(void* dev, int value, size_t bytes, void* stream) {
+  HIP_TRY(SODA_HIP_ERR_DEVICE_RUN, hipMemsetAsync(dev, value, bytes, as_stream(stream)));
+  return 0;
+}
+
+int soda_hip_memcpy_h2d(void* dev, const void* host, size_t bytes, void* stream) {
+  HIP_TRY(SODA_HIP_ERR_COPY_TO_DEVICE,
+          hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+  return 0;
+}
+
+int soda_hip_memcpy_d2h(void* host, const void* dev, size_t bytes, void* stream) {
+  HIP_TRY(SODA_HIP_ERR_COPY_TO_HOST,
+          hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+  return 0;
+}
+
+int soda_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+  HIP_TRY(SODA_HIP_ERR_DEVICE_RUN,
+          hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+  return 0;
+}
+
+int soda_hip_stream_synchronize(void* stream) {
+  HIP_TRY(SODA_HIP_ERR_DEVICE_SYNC, hipStreamSynchronize(as_stream(stream)));
+  return 0;
+}
+
+// ---------------------------------------------------------------- modules
+static int finish_module(soda_hip_module* m, soda_hip_module** out) {
+  hipError_t e = hipModuleLoadData(&m->mod, m->image.data());
+  if (e != hipSuccess) {
+    delete m;
+    return fail(SODA_HIP_ERR_MODULE, "hipModuleLoadData: %s", hipGetErrorString(e));
+  }
+  hipDeviceptr_t ptr = nullptr;
+  size_t bytes = 0;
+  if (hipModuleGetGlobal(&ptr, &bytes, m->mod, "soda_hip_meta") == hipSuccess && bytes) {
+    m->meta.resize(bytes);
+    if (hipMemcpyDtoH(&m->meta[0], ptr, bytes) != hipSuccess) m->meta.clear();
+    const size_t z = m->meta.find('\0');
+    if (z != std::string::npos) m->meta.resize(z);
+  }
+  (void)hipGetLastError();
+  *out = m;
+  return 0;
+}
+
+int soda_hip_module_load_data(const void* image, size_t bytes, soda_hip_module** module) {
+  if (!image || !module) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  soda_hip_module* m = new soda_hip_module;
+  m->image.assign((const char*)image, (const char*)image + bytes);
+  return finish_module(m, module);
+}
+
+int soda_hip_module_load_file(const char* path, soda_hip_module** module) {
+  if (!path || !module) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(SODA_HIP_ERR_MODULE, "cannot open %s", path);
+  std::vector<char> data;
+  char buf[1 << 16];
+  size_t n;
+  while ((n = fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + n);
+  fclose(f);
+  if (data.empty()) return fail(SODA_HIP_ERR_MODULE, "%s is empty", path);
+  return soda_hip_module_load_data(data.data(), data.size(), module);
+}
+
+int soda_hip_module_compile(const char* source, const char* arch,
+                            const char* const* options, int n_options,
+                            soda_hip_module** module) {
+  if (!source || !module) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  std::string arch_flag = "--offload-arch=";
+  if (arch && *arch) {
+    arch_flag += arch;
+  } else {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(SODA_HIP_ERR_NO_DEVICE, hipGetDevice(&dev));
+    HIP_TRY(SODA_HIP_ERR_NO_DEVICE, hipGetDeviceProperties(&prop, dev));
+    arch_flag += prop.gcnArchName;
+  }
+  std::vector<const char*> opts = {arch_flag.c_str(), "-O3", "-ffp-contract=off",
+                                   "-std=c++17"};
+  for (int i = 0; i < n_options; ++i) opts.push_back(options[i]);
+  hiprtcProgram prog;
+  hiprtcResult r = hiprtcCreateProgram(&prog, source, "soda_kernel.hip", 0, nullptr, nullptr);
+  if (r != HIPRTC_SUCCESS)
+    return fail(SODA_HIP_ERR_COMPILE, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
+  r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+  if (r != HIPRTC_SUCCESS) {
+    size_t log_size = 0;
+    hiprtcGetProgramLogSize(prog, &log_size);
+    std::string log(log_size, '\0');
+    if (log_size) hiprtcGetProgramLog(prog, &log[0]);
+    hiprtcDestroyProgram(&prog);
+    return fail(SODA_HIP_ERR_COMPILE, "hiprtc: %s\n%.900s", hiprtcGetErrorString(r),
+                log.c_str());
+  }
+  size_t code_size = 0;
+  hiprtcGetCodeSize(prog, &code_size);
+  soda_hip_module* m = new soda_hip_module;
+  m->image.resize(code_size);
+  hiprtcGetCode(prog, m->image.data());
+  hiprtcDestroyProgram(&prog);
+  return finish_module(m, module);
+}
+
+int soda_hip_module_image(const soda_hip_module* module, const void** image, size_t* bytes) {
+  if (!module || !image || !bytes) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  *image = module->image.data();
+  *bytes = module->image.size();
+  return 0;
+}
+
+int soda_hip_module_meta(const soda_hip_module* module, char* buf, size_t cap, size_t* length) {
+  if (!module) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "module is NULL");
+  if (length) *length = module->meta.size();
+  if (buf && cap) {
+    const size_t n = std::min(cap - 1, module->meta.size());
+    memcpy(buf, module->meta.data(), n);
+    buf[n] = '\0';
+  }
+  return 0;
+}
+
+int soda_hip_module_unload(soda_hip_module* module) {
+  if (!module) return 0;
+  if (module->mod) HIP_TRY(SODA_HIP_ERR_MODULE, hipModuleUnload(module->mod));
+  delete module;
+  return 0;
+}
+
+// ------------------------------------------------------------------ plans
+int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* program,
+                         const soda_hip_kernel* kernels, int n_kernels,
+                         soda_hip_plan** plan) {
+  if (!module || !program || !kernels || !plan)
+    return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  const soda_hip_program& p = *program;
+  if (p.dim < 1 || p.dim > 3)
+    return fail(SODA_HIP_ERR_CONSTRAINT, "dim %d not supported (1..3)", p.dim);
+  if (p.n_inputs < 1 || p.n_stages < 1 || p.n_outputs < 1 ||
+      p.n_inputs + p.n_stages > SODA_HIP_MAX_TENSORS || p.n_outputs > SODA_HIP_MAX_IO ||
+      p.n_inputs > SODA_HIP_MAX_IO || p.n_windows < 1 || p.n_windows > SODA_HIP_MAX_WINDOWS)
+    return fail(SODA_HIP_ERR_CONSTRAINT, "program descriptor out of range");
+  if (n_kernels < 1 || n_kernels > SODA_HIP_MAX_KERNELS)
+    return fail(SODA_HIP_ERR_CONSTRAINT, "n_kernels %d out of range", n_kernels);
+  for (int j = 0; j < p.n_outputs; ++j)
+    if (p.output_tensor[j] < p.n_inputs || p.output_tensor[j] >= p.n_inputs + p.n_stages)
+      return fail(SODA_HIP_ERR_CONSTRAINT, "output %d is not a stage", j);
+  for (int w = 0; w < p.n_windows; ++w) {
+    const soda_hip_window& win = p.window[w];
+    if (win.stage < p.n_inputs || win.stage >= p.n_inputs + p.n_stages ||
+        win.parent < 0 || win.parent >= win.stage)
+      return fail(SODA_HIP_ERR_CONSTRAINT, "window %d breaks execution order", w);
+  }
+  soda_hip_plan* pl = new soda_hip_plan;
+  pl->module = module;
+  pl->prog = p;
+  pl->kernels.assign(kernels, kernels + n_kernels);
+  pl->funcs.resize(n_kernels);
+  for (int k = 0; k < n_kernels; ++k) {
+    pl->kernels[k].name[sizeof(pl->kernels[k].name) - 1] = '\0';
+    hipError_t e = hipModuleGetFunction(&pl->funcs[k], module->mod, pl->kernels[k].name);
+    if (e != hipSuccess) {
+      std::string name = pl->kernels[k].name;
+      delete pl;
+      return fail(SODA_HIP_ERR_NO_KERNEL, "kernel `%s` is not in the blob: %s",
+                  name.c_str(), hipGetErrorString(e));
+    }
+    const soda_hip_kernel& d = pl->kernels[k];
+    if (d.block[0] < 1 || d.block[1] < 1 || d.block[2] < 1 ||
+        (int64_t)d.block[0] * d.block[1] * d.block[2] > 1024) {
+      delete pl;
+      return fail(SODA_HIP_ERR_CONSTRAINT, "kernel %d has a bad block shape", k);
+    }
+  }
+  *plan = pl;
+  return 0;
+}
+
+int soda_hip_plan_destroy(soda_hip_plan* plan) {
+  if (!plan) return 0;
+  int rc = 0;
+  for (void* ptr : plan->scratch)
+    if (ptr && hipFree(ptr) != hipSuccess)
+      rc = fail(SODA_HIP_ERR_DEVICE_FREE, "hipFree of plan scratch failed");
+  delete plan;
+  return rc;
+}
+
+int soda_hip_plan_margins(const soda_hip_plan* plan, int iterations,
+                          int32_t lo[SODA_HIP_MAX_DIMS], int32_t hi[SODA_HIP_MAX_DIMS]) {
+  if (!plan || !lo || !hi) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  if (iterations < 0) return fail(SODA_HIP_ERR_CONSTRAINT, "iterations < 0");
+  output_margins(const_cast<soda_hip_plan*>(plan), iterations, lo, hi);
+  return 0;
+}
+
+int soda_hip_plan_set_max_depth(soda_hip_plan* plan, int max_depth) {
+  if (!plan) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "plan is NULL");
+  plan->max_depth = max_depth;
+  return 0;
+}
+
+int soda_hip_sweep(soda_hip_plan* plan, void* const* in, void* const* out,
+                   const int64_t dims[SODA_HIP_MAX_DIMS], int iterate,
+                   const int32_t* valid_lo, const int32_t* valid_hi, void* stream) {
+  if (!plan || !in || !out || !dims) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  std::vector<Launch> list;
+  int depth = 0;
+  int rc = build_schedule(plan, in, out, dims, iterate, valid_lo, valid_hi, &list, &depth);
+  if (rc) return rc;
+  for (const Launch& l : list) {
+    rc = launch_one(plan, l, as_stream(stream));
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int soda_hip_sweep_timed(soda_hip_plan* plan, void* const* in, void* const* out,
+                         const int64_t dims[SODA_HIP_MAX_DIMS], int iterate,
+                         int warmup, int repeats, void* stream,
+                         soda_hip_timing* timing) {
+  if (!plan || !in || !out || !dims) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  if (repeats < 1) return fail(SODA_HIP_ERR_CONSTRAINT, "repeats must be >= 1");
+  hipStream_t s = as_stream(stream);
+  std::vector<Launch> list;
+  int depth = 0;
+  int rc = build_schedule(plan, in, out, dims, iterate, nullptr, nullptr, &list, &depth);
+  if (rc) return rc;
+  for (int w = 0; w < warmup; ++w)
+    for (const Launch& l : list)
+      if ((rc = launch_one(plan, l, s))) return rc;
+  // one event before every launch and one after the last, per repeat
+  const size_t per = list.size() + 1;
+  std::vector<hipEvent_t> ev(per * repeats);
+  for (auto& e : ev) HIP_TRY(SODA_HIP_ERR_DEVICE_RUN, hipEventCreate(&e));
+  for (int r = 0; r < repeats && !rc; ++r) {
+    for (size_t i = 0; i < list.size() && !rc; ++i) {
+      if (hipEventRecord(ev[r * per + i], s) != hipSuccess)
+        rc = fail(SODA_HIP_ERR_DEVICE_RUN, "hipEventRecord failed");
+      else
+        rc = launch_one(plan, list[i], s);
+    }
+    if (!rc && hipEventRecord(ev[r * per + list.size()], s) != hipSuccess)
+      rc = fail(SODA_HIP_ERR_DEVICE_RUN, "hipEventRecord failed");
+  }
+  if (!rc && hipStreamSynchronize(s) != hipSuccess)
+    rc = fail(SODA_HIP_ERR_DEVICE_SYNC, "hipStreamSynchronize failed: %s",
+              hipGetErrorString(hipGetLastError()));
+  if (!rc && timing) {
+    memset(timing, 0, sizeof *timing);
+    double total_ms = 0;
+    std::map<int, std::pair<double, int>> per_kernel;
+    for (int r = 0; r < repeats; ++r) {
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, ev[r * per], ev[r * per + list.size()]);
+      total_ms += ms;
+      for (size_t i = 0; i < list.size(); ++i) {
+        float k_ms = 0;
+        (void)hipEventElapsedTime(&k_ms, ev[r * per + i], ev[r * per + i + 1]);
+        auto& slot = per_kernel[list[i].kernel];
+        slot.first += k_ms;
+        slot.second += 1;
+      }
+    }
+    timing->kernel_us = total_ms * 1000.0 / repeats;
+    timing->launches = (int)list.size();
+    timing->max_depth = depth;
+    int best = -1;
+    for (auto& kv : per_kernel)
+      if (best < 0 || kv.second.first > per_kernel[best].first) best = kv.first;
+    if (best >= 0) {
+      timing->dominant_us = per_kernel[best].first * 1000.0;
+      timing->dominant_launches = per_kernel[best].second;
+      snprintf(timing->dominant_name, sizeof timing->dominant_name, "%s",
+               plan->kernels[best].name);
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+// ------------------------------------------------- host-buffer entry point
+int soda_hip_run_buffers(soda_hip_plan* plan, soda_hip_buffer_t* const* inputs,
+                         soda_hip_buffer_t* const* outputs, int iterate,
+                         soda_hip_timing* timing) {
+  if (!plan || !inputs || !outputs) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  const soda_hip_program& p = plan->prog;
+  for (int j = 0; j < p.n_inputs; ++j)
+    if (!inputs[j]) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "input buffer %d is NULL", j);
+  for (int j = 0; j < p.n_outputs; ++j)
+    if (!outputs[j]) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "output buffer %d is NULL", j);
+  int32_t mlo[SODA_HIP_MAX_DIMS], mhi[SODA_HIP_MAX_DIMS];
+  if (iterate < 1) return fail(SODA_HIP_ERR_CONSTRAINT, "iterate must be >= 1");
+  output_margins(plan, iterate, mlo, mhi);
+
+  // bounds-query mode (host.py:204-252): a buffer with neither host nor device
+  // memory only gets its required shape filled in.  Outputs keep their extents,
+  // inputs need the outputs' extents plus the stencil window minus one.
+  bool query = false;
+  auto is_null = [](const soda_hip_buffer_t* b) { return b->host == nullptr && b->dev == 0; };
+  for (int j = 0; j < p.n_outputs; ++j) query |= is_null(outputs[j]);
+  for (int j = 0; j < p.n_inputs; ++j) query |= is_null(inputs[j]);
+  if (query) {
+    const soda_hip_buffer_t* o0 = outputs[0];
+    for (int j = 0; j < p.n_outputs; ++j) {
+      soda_hip_buffer_t* b = outputs[j];
+      if (!is_null(b)) continue;
+      int32_t stride = 1;
+      for (int d = 0; d < 4; ++d) {
+        if (d < p.dim) { b->stride[d] = stride; stride *= b->extent[d]; }
+        else { b->min[d] = b->extent[d] = b->stride[d] = 0; }
+      }
+      b->elem_size = p.elem_size[p.output_tensor[j]];
+    }
+    for (int j = 0; j < p.n_inputs; ++j) {
+      soda_hip_buffer_t* b = inputs[j];
+      if (!is_null(b)) continue;
+      int32_t stride = 1;
+      for (int d = 0; d < 4; ++d) {
+        if (d < p.dim) {
+          b->min[d] = o0->min[d];
+          b->extent[d] = o0->extent[d] + mlo[d] + mhi[d];
+          b->stride[d] = stride;
+          stride *= b->extent[d];
+        } else {
+          b->min[d] = b->extent[d] = b->stride[d] = 0;
+        }
+      }
+      b->elem_size = p.elem_size[j];
+    }
+    return 0;
+  }
+
+  // element-size checks (host.py:254-255, :969-982)
+  for (int j = 0; j < p.n_outputs; ++j)
+    if (outputs[j]->elem_size != p.elem_size[p.output_tensor[j]]) {
+      fprintf(stderr, "Buffer output %d has elem_size %d instead of %d", j,
+              outputs[j]->elem_size, p.elem_size[p.output_tensor[j]]);
+      return fail(SODA_HIP_ERR_BAD_ELEM_SIZE, "output %d: elem_size %d, expected %d", j,
+                  outputs[j]->elem_size, p.elem_size[p.output_tensor[j]]);
+    }
+  for (int j = 0; j < p.n_inputs; ++j)
+    if (inputs[j]->elem_size != p.elem_size[j]) {
+      fprintf(stderr, "Buffer input %d has elem_size %d instead of %d", j,
+              inputs[j]->elem_size, p.elem_size[j]);
+      return fail(SODA_HIP_ERR_BAD_ELEM_SIZE, "input %d: elem_size %d, expected %d", j,
+                  inputs[j]->elem_size, p.elem_size[j]);
+    }
+  int64_t dims[SODA_HIP_MAX_DIMS] = {1, 1, 1, 1};
+  size_t cells = 1;
+  for (int d = 0; d < p.dim; ++d) {
+    dims[d] = inputs[0]->extent[d];
+    if (dims[d] <= 0) return fail(SODA_HIP_ERR_CONSTRAINT, "extent[%d] = %lld", d,
+                                  (long long)dims[d]);
+    cells *= (size_t)dims[d];
+  }
+  auto dense = [&](const soda_hip_buffer_t* b, const char* what, int j) -> int {
+    int64_t stride = 1;
+    for (int d = 0; d < p.dim; ++d) {
+      if (b->extent[d] != dims[d])
+        return fail(SODA_HIP_ERR_CONSTRAINT, "%s %d: extent[%d] = %d, expected %lld", what,
+                    j, d, b->extent[d], (long long)dims[d]);
+      if (b->stride[d] != stride)
+        return fail(SODA_HIP_ERR_CONSTRAINT, "%s %d: stride[%d] = %d, expected %lld "
+                    "(dense row-major arrays only)", what, j, d, b->stride[d],
+                    (long long)stride);
+      stride *= dims[d];
+    }
+    if (!b->host) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "%s %d has no host memory", what, j);
+    return 0;
+  };
+  for (int j = 0; j < p.n_inputs; ++j) { int rc = dense(inputs[j], "input", j); if (rc) return rc; }
+  for (int j = 0; j < p.n_outputs; ++j) { int rc = dense(outputs[j], "output", j); if (rc) return rc; }
+
+  std::vector<void*> din(p.n_inputs, nullptr), dout(p.n_outputs, nullptr);
+  int rc = 0;
+  auto cleanup = [&]() {
+    for (void* q : din) if (q) (void)hipFree(q);
+    for (void* q : dout) if (q) (void)hipFree(q);
+  };
+  for (int j = 0; j < p.n_inputs && !rc; ++j) {
+    const size_t bytes = cells * p.elem_size[j];
+    if (hipMalloc(&din[j], bytes) != hipSuccess)
+      rc = fail(SODA_HIP_ERR_DEVICE_MALLOC, "hipMalloc(%zu) failed", bytes);
+    else if (hipMemcpy(din[j], inputs[j]->host, bytes, hipMemcpyHostToDevice) != hipSuccess)
+      rc = fail(SODA_HIP_ERR_COPY_TO_DEVICE, "H2D copy of input %d failed", j);
+  }
+  for (int j = 0; j < p.n_outputs && !rc; ++j) {
+    const size_t bytes = cells * p.elem_size[p.output_tensor[j]];
+    if (hipMalloc(&dout[j], bytes) != hipSuccess)
+      rc = fail(SODA_HIP_ERR_DEVICE_MALLOC, "hipMalloc(%zu) failed", bytes);
+    else if (hipMemset(dout[j], 0, bytes) != hipSuccess)
+      rc = fail(SODA_HIP_ERR_DEVICE_RUN, "hipMemset failed");
+  }
+  soda_hip_timing local;
+  if (!rc) rc = soda_hip_sweep_timed(plan, din.data(), dout.data(), dims, iterate, 1, 1,
+                                     nullptr, &local);
+  if (!rc) {
+    // host.py:796-800: pixels = product of input extents, not multiplied by iterate
+    printf("Kernel execution time: %lf us\n", local.kernel_us);
+    printf("Kernel throughput: %lf pixel/ns\n", (double)cells / local.kernel_us / 1e3);
+    fflush(stdout);
+    if (timing) *timing = local;
+  }
+  // only the valid interior goes back to the caller (host.py:838-899)
+  for (int j = 0; j < p.n_outputs && !rc; ++j) {
+    const int es = p.elem_size[p.output_tensor[j]];
+    int64_t lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1}, ext[3] = {1, 1, 1};
+    bool empty = false;
+    for (int d = 0; d < p.dim; ++d) {
+      lo[d] = mlo[d]; hi[d] = dims[d] - mhi[d]; ext[d] = dims[d];
+      if (hi[d] <= lo[d]) empty = true;
+    }
+    if (empty) continue;
+    hipMemcpy3DParms parms;
+    memset(&parms, 0, sizeof parms);
+    parms.srcPtr = make_hipPitchedPtr(dout[j], ext[0] * es, ext[0] * es, ext[1]);
+    parms.dstPtr = make_hipPitchedPtr(outputs[j]->host, ext[0] * es, ext[0] * es, ext[1]);
+    parms.srcPos = make_hipPos(lo[0] * es, lo[1], lo[2]);
+    parms.dstPos = make_hipPos(lo[0] * es, lo[1], lo[2]);
+    parms.extent = make_hipExtent((hi[0] - lo[0]) * es, hi[1] - lo[1], hi[2] - lo[2]);
+    parms.kind = hipMemcpyDeviceToHost;
+    if (hipMemcpy3D(&parms) != hipSuccess)
+      rc = fail(SODA_HIP_ERR_COPY_TO_HOST, "D2H copy of output %d failed: %s", j,
+                hipGetErrorString(hipGetLastError()));
+  }
+  cleanup();
+  return rc;
+}
+
+}  // extern "C"
