@@ -1,0 +1,93 @@
+"""HIP kernel printer: program spec -> one translation unit of gfx950 kernels.
+
+Counterpart of the reference's HLS kernel printer (reference
+src/soda/codegen/xilinx/hls_kernel.py:146-189): same input (the analysed
+stencil), and the arithmetic of every stage is the same expression text
+(hls_kernel.py:487-489 `WriteData(..., c_type(expr.c_expr))`); everything around
+it is designed for a GPU instead of an FPGA dataflow region.
+
+The unit holds
+  * one per-stage kernel per stage (kernel_stage.py), always;
+  * fused kernels of depth 1, 2, 4, ... (kernel_stream2d.py) when the program
+    is in their scope;
+  * `soda_hip_meta`, JSON describing the program and the kernel table, which
+    libsoda_hip.so reads back from the loaded blob.
+"""
+import os
+import subprocess
+import tempfile
+
+from .. import __version__
+from . import kernel_common, kernel_stage, kernel_stream2d
+from . import spec as specmod
+
+DEFAULT_MAX_DEPTH = 16
+
+HIPCC_FLAGS = ['-x', 'hip', '--offload-arch=gfx950', '--cuda-device-only',
+               '--no-gpu-bundle-output', '-O3', '-ffp-contract=off',
+               '-fno-slp-vectorize', '-std=c++17']
+
+
+def default_cols(spec):
+  """Columns per lane: the widest vector (<= 16 bytes) the DSL's burst width
+  allows; `burst width: 512` (64 bytes per FPGA burst) gives 16-byte lanes."""
+  elem = specmod.ELEM_SIZE[spec['inputs'][0]['c_type']]
+  vec = max(elem, min(16, spec['burst_width'] // 8))
+  return max(1, vec // elem)
+
+
+def fused_depths(spec, max_depth):
+  if len(spec['inputs']) == 1 and len(spec['outputs']) == 1 and \
+      spec['inputs'][0]['c_type'] == specmod.tensor_c_types(spec)[spec['outputs'][0]]:
+    out, d = [], 1
+    # no point in a kernel deeper than the program iterates
+    while d <= max_depth and d <= max(1, spec['iterate']):
+      out.append(d)
+      d *= 2
+    return out
+  return [1]
+
+
+def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
+             fused=True):
+  """Returns (kernel text, kernel table)."""
+  max_depth = DEFAULT_MAX_DEPTH if max_depth is None else max_depth
+  parts = [kernel_common.prelude(spec, __version__)]
+  wrappers = kernel_common.math_wrappers(kernel_common.used_functions(spec))
+  if wrappers:
+    parts.append('// math calls resolve as in the reference CPU path: C double '
+                 'functions\n' + '\n'.join(wrappers) + '\n')
+  text, table = kernel_stage.emit(spec)
+  parts.append(text)
+  notes = []
+  if fused and spec['dim'] == 2:
+    for depth in fused_depths(spec, max_depth):
+      try:
+        ftext, entry = kernel_stream2d.emit(
+            spec, depth, cols=cols if cols else default_cols(spec),
+            chunk_rows=chunk_rows or 256,
+            prefetch=3 if prefetch is None else prefetch)
+      except kernel_stream2d.NotFusable as e:
+        notes.append('depth %d not fused: %s' % (depth, e))
+        break
+      parts.append(ftext)
+      table.append(entry)
+  if notes:
+    parts.append(''.join('// %s\n' % n for n in notes))
+  parts.append(kernel_common.meta_symbol(spec, table))
+  return '\n'.join(parts), table
+
+
+def compile_to_code_object(text, out_path, hipcc=None, extra_flags=()):
+  """Offline build of the blob (the role `--xocl-hw-xo` plays in the reference:
+  invoking the vendor tool chain from the compiler driver)."""
+  hipcc = hipcc or os.environ.get('HIPCC') or '/opt/rocm/bin/hipcc'
+  with tempfile.NamedTemporaryFile('w', suffix='.hip', delete=False) as f:
+    f.write(text)
+    src = f.name
+  try:
+    subprocess.check_call([hipcc] + HIPCC_FLAGS + list(extra_flags) +
+                          [src, '-o', out_path])
+  finally:
+    os.unlink(src)
+  return out_path

@@ -1,0 +1,223 @@
+"""Pieces shared by every generated HIP kernel: the include-free prelude, type
+and math-call rewriting of expression text, the embedded metadata symbol.
+
+The generated translation unit has no `#include`: it must compile both offline
+(`hipcc -x hip --cuda-device-only`, at `sodac` time) and at run time through
+hiprtc (libsoda_hip.so), so it spells HIP's keywords as the clang attributes
+they expand to and uses the amdgcn builtins for work-item ids.
+"""
+import hashlib
+import json
+import re
+
+from . import spec as specmod
+
+ABI_VERSION = 1
+
+# element types as builtin spellings (no <stdint.h> in the translation unit)
+BUILTIN_TYPE = {
+    'uint8_t': 'unsigned char', 'int8_t': 'signed char',
+    'uint16_t': 'unsigned short', 'int16_t': 'short',
+    'uint32_t': 'unsigned int', 'int32_t': 'int',
+    'uint64_t': 'unsigned long long', 'int64_t': 'long long',
+    'float': 'float', 'double': 'double', '_Float16': '_Float16',
+}
+_TYPE_RE = re.compile(r'\b(u?int(?:8|16|32|64)_t)\b')
+
+# Math calls.  The reference's CPU path compiles the expression text as C++ with
+# <cmath> but without `using namespace std` (reference host.py:12-36), so an
+# unqualified `sqrt(x)` on a float is the C function `double sqrt(double)`:
+# the argument is promoted and the rest of the expression continues in double.
+# The wrappers below reproduce exactly that overload set on the device.
+_DOUBLE_UNARY = ('cos sin tan acos asin atan cosh sinh tanh acosh asinh atanh exp '
+                 'log log10 exp2 expm1 log1p log2 logb cbrt erf erfc tgamma lgamma '
+                 'ceil floor trunc round rint nearbyint fabs sqrt').split()
+_DOUBLE_BINARY = ('atan2 pow hypot fmod remainder copysign nextafter fdim fmax '
+                  'fmin').split()
+_CALL_RE = re.compile(r'\b(%s)\s*\(' % '|'.join(
+    _DOUBLE_UNARY + _DOUBLE_BINARY + ['fma', 'abs', 'min', 'max', 'select']))
+
+
+def builtin_type(c_type):
+  return BUILTIN_TYPE[c_type]
+
+
+def device_expr(text):
+  """Expression text of the spec -> device C++ (loads still as placeholders)."""
+  text = _TYPE_RE.sub(lambda m: BUILTIN_TYPE[m.group(1)], text)
+  return _CALL_RE.sub(lambda m: 'soda_fn_%s(' % m.group(1), text)
+
+
+def used_functions(spec):
+  found = set()
+  for stage in spec['stages']:
+    for text in [stage['expr']] + [l['expr'] for l in stage['lets']]:
+      found.update(m.group(1) for m in _CALL_RE.finditer(text))
+  return found
+
+
+def math_wrappers(names):
+  out = []
+  for name in sorted(names):
+    if name == 'sqrt':
+      out.append('DEV double soda_fn_sqrt(double x) { return __builtin_sqrt(x); }')
+    elif name == 'fabs':
+      out.append('DEV double soda_fn_fabs(double x) { return __builtin_fabs(x); }')
+    elif name in ('floor', 'ceil', 'trunc', 'rint', 'nearbyint', 'round'):
+      out.append('DEV double soda_fn_%s(double x) { return __builtin_%s(x); }'
+                 % (name, name))
+    elif name in _DOUBLE_UNARY:
+      out.append('extern "C" __attribute__((device)) double __ocml_%s_f64(double);'
+                 % name)
+      out.append('DEV double soda_fn_%s(double x) { return __ocml_%s_f64(x); }'
+                 % (name, name))
+    elif name in ('fmax', 'fmin', 'copysign'):
+      out.append('DEV double soda_fn_%s(double x, double y) '
+                 '{ return __builtin_%s(x, y); }' % (name, name))
+    elif name in _DOUBLE_BINARY:
+      out.append('extern "C" __attribute__((device)) double '
+                 '__ocml_%s_f64(double, double);' % name)
+      out.append('DEV double soda_fn_%s(double x, double y) '
+                 '{ return __ocml_%s_f64(x, y); }' % (name, name))
+    elif name == 'fma':
+      out.append('DEV double soda_fn_fma(double x, double y, double z) '
+                 '{ return __builtin_fma(x, y, z); }')
+    elif name == 'abs':   # <cstdlib>'s int abs(int) is the visible one
+      out.append('DEV int soda_fn_abs(int x) { return x < 0 ? -x : x; }')
+    elif name in ('min', 'max'):
+      cmp = '<' if name == 'min' else '>'
+      out.append('template <typename A, typename B> DEV auto soda_fn_%s(A a, B b) '
+                 '-> decltype(a + b) { return (b %s a) ? b : a; }' % (name, cmp))
+    elif name == 'select':
+      out.append('template <typename C, typename A, typename B> DEV auto '
+                 'soda_fn_select(C c, A a, B b) -> decltype(a + b) '
+                 '{ return c ? a : b; }')
+  return out
+
+
+def program_hash(spec):
+  """Identity of what a blob computes: stages, types, windows.  Tuning knobs
+  (burst width, unroll factor, tile size, iterate) are deliberately excluded;
+  the reference ties kernel and host together with -D guards instead
+  (reference hls_kernel.py:154-160)."""
+  essential = dict(
+      app_name=spec['app_name'], dim=spec['dim'],
+      inputs=[(t['name'], t['c_type']) for t in spec['inputs']],
+      outputs=spec['outputs'],
+      stages=[(s['name'], s['c_type'], s['expr'],
+               [(l['name'], l['c_type'], l['expr']) for l in s['lets']])
+              for s in spec['stages']])
+  return hashlib.sha1(json.dumps(essential, sort_keys=True).encode()).hexdigest()
+
+
+PRELUDE = '''\
+// Generated by sodac (SODA HIP back end, soda_hip %(version)s) for gfx950.
+// kernel: %(app)s    program hash: %(hash)s
+// Compile: hipcc -x hip --offload-arch=gfx950 --cuda-device-only \\
+//          --no-gpu-bundle-output -O3 -ffp-contract=off -std=c++17
+// or hand this text to libsoda_hip.so (hiprtc).  -ffp-contract=off is part of
+// the contract: the arithmetic must not be fused.
+#define GLOBAL extern "C" __attribute__((global))
+#define DEV static __attribute__((device)) inline __attribute__((always_inline))
+#define WG_SIZE(n) __attribute__((amdgpu_flat_work_group_size(n, n)))
+typedef long long i64;
+
+// by-value kernel argument; layout = soda_hip_args of include/soda_hip.h
+struct soda_hip_args {
+  void* tensor[16];
+  i64 dims[4];
+  i64 box_lo[4];
+  i64 box_hi[4];
+};
+
+DEV int lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// value of `v` in lane-1 / lane+1 of the 64-lane wavefront (DPP wave shifts;
+// the lane with no such neighbour receives 0)
+DEV int dpp_from_below(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+DEV int dpp_from_above(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+template <typename T, bool BELOW> DEV T lane_neighbour(T v) {
+  if constexpr (sizeof(T) == 4) {
+    const int w = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(T, BELOW ? dpp_from_below(w) : dpp_from_above(w));
+  } else if constexpr (sizeof(T) == 8) {
+    struct halves { int lo, hi; };
+    halves h = __builtin_bit_cast(halves, v);
+    h.lo = BELOW ? dpp_from_below(h.lo) : dpp_from_above(h.lo);
+    h.hi = BELOW ? dpp_from_below(h.hi) : dpp_from_above(h.hi);
+    return __builtin_bit_cast(T, h);
+  } else if constexpr (sizeof(T) == 2) {
+    const int w = __builtin_bit_cast(unsigned short, v);
+    return __builtin_bit_cast(T, (unsigned short)(BELOW ? dpp_from_below(w)
+                                                        : dpp_from_above(w)));
+  } else {
+    const int w = __builtin_bit_cast(unsigned char, v);
+    return __builtin_bit_cast(T, (unsigned char)(BELOW ? dpp_from_below(w)
+                                                       : dpp_from_above(w)));
+  }
+}
+template <typename T> DEV T from_lane_below(T v) { return lane_neighbour<T, true>(v); }
+template <typename T> DEV T from_lane_above(T v) { return lane_neighbour<T, false>(v); }
+'''
+
+
+def prelude(spec, version):
+  return PRELUDE % dict(version=version, app=spec['app_name'],
+                        hash=program_hash(spec))
+
+
+def meta_symbol(spec, kernels, extra=None):
+  """`soda_hip_meta`: JSON the run time reads back from the loaded blob."""
+  meta = dict(abi=ABI_VERSION, program_hash=program_hash(spec),
+              app_name=spec['app_name'], kernels=kernels, spec=spec)
+  if extra:
+    meta.update(extra)
+  text = json.dumps(meta, sort_keys=True, separators=(',', ':'))
+  escaped = text.replace('\\', '\\\\').replace('"', '\\"')
+  # split into adjacent literals to keep lines readable
+  chunks = [escaped[i:i + 100] for i in range(0, len(escaped), 100)]
+  # never split inside an escape sequence
+  fixed = []
+  carry = ''
+  for ch in chunks:
+    ch = carry + ch
+    carry = ''
+    n = len(ch) - len(ch.rstrip('\\'))
+    if n % 2 == 1:
+      carry = '\\'
+      ch = ch[:-1]
+    fixed.append(ch)
+  if carry:
+    fixed.append(carry)
+  body = '\n'.join('    "%s"' % ch for ch in fixed)
+  return ('extern "C" __attribute__((device)) __attribute__((used)) '
+          'const char soda_hip_meta[] =\n%s;\n' % body)
+
+
+def read_meta_from_source(text):
+  """Recovers the metadata JSON from generated kernel TEXT (no device needed)."""
+  m = re.search(r'soda_hip_meta\[\] =\n((?:    ".*"\n?)+);', text)
+  if not m:
+    raise ValueError('no soda_hip_meta in kernel text')
+  raw = ''.join(line.strip()[1:-1] for line in m.group(1).splitlines()
+                if line.strip())
+  return json.loads(raw.replace('\\"', '"').replace('\\\\', '\\'))
+
+
+def tensor_index(spec):
+  names = [t['name'] for t in spec['inputs']] + [s['name'] for s in spec['stages']]
+  return {n: i for i, n in enumerate(names)}
+
+
+def elem_sizes(spec):
+  types = specmod.tensor_c_types(spec)
+  idx = tensor_index(spec)
+  out = [0] * len(idx)
+  for n, i in idx.items():
+    out[i] = specmod.ELEM_SIZE[types[n]]
+  return out

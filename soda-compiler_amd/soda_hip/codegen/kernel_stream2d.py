@@ -1,0 +1,318 @@
+"""Fused 2-D kernels: all stages of `depth` iterations in one launch, streaming
+along the outer dimension with every intermediate kept in registers.
+
+This is the GPU counterpart of the micro-architecture the reference synthesises
+for an FPGA (line buffers + one compute module per stage per iteration, chained;
+reference src/soda/core.py:612-777, src/soda/dataflow.py:122-346, README
+"iterate" = replicated pipeline stages): the chain of stage instances is the
+same, but the "line buffers" are per-lane register windows and the "FIFOs between
+modules" are the program order of one wavefront.
+
+Mapping (gfx950, wave64):
+  * one wavefront owns a strip of 64*C columns; lane l holds C consecutive
+    columns of every live row, so a row load is one coalesced `C*sizeof(T)`-byte
+    vector load per lane (1 KiB per wave for 16-byte vectors);
+  * x-neighbours inside a lane are other registers; across lanes they come from
+    lane-1 / lane+1 through DPP wave shifts fused into the consuming VALU op --
+    no LDS, no barrier, nothing shared between wavefronts;
+  * the wavefront walks down its strip one input row per step.  Stage instance S
+    trails the load head by lag(S) rows and keeps keep(S) rows for its readers
+    (the register analogue of the reference's reuse-buffer lengths); the y loop
+    is unrolled by the rotation period so that "shifting" a window is renaming;
+  * strips overlap by the composed x-window of `depth` iterations and y-chunks
+    by the composed y-window (overlapped tiling: halo cells are recomputed, never
+    exchanged), so HBM sees one read and one write per cell per `depth` updates.
+
+Cost model per cell-update (jacobi2d): 5 VALU lane-ops, 8/depth bytes of HBM.
+"""
+import math
+
+from . import spec as specmod
+from .kernel_common import builtin_type, device_expr, tensor_index
+
+WAVES_PER_BLOCK = 4
+LANES = 64
+
+
+class NotFusable(Exception):
+  """The program is outside what this generator covers; per-stage kernels
+  remain available."""
+
+
+class Instance:
+  """One tensor of one iteration inside the fused pipeline."""
+
+  def __init__(self, ident, tensor, iteration, c_type, stage=None):
+    self.ident = ident          # C identifier stem
+    self.tensor = tensor
+    self.iteration = iteration
+    self.c_type = c_type
+    self.stage = stage          # spec stage dict, None for a loaded input
+    self.reads = []             # [(Instance, (dx, dy), name in expr)], unique
+    self.lag = 0                # rows behind the load head
+    self.keep = 0               # rows retained for readers (0 = stored directly)
+    self.final = False          # last iteration's output: goes to HBM
+
+
+def build_pipeline(spec, depth, prefetch):
+  if spec['dim'] != 2:
+    raise NotFusable('stream2d handles 2-D programs')
+  if len(spec['outputs']) != 1:
+    raise NotFusable('stream2d handles single-output programs')
+  ins = [t['name'] for t in spec['inputs']]
+  if depth > 1 and len(ins) != 1:
+    raise NotFusable('depth > 1 needs one input feeding one output')
+  types = specmod.tensor_c_types(spec)
+  for name, ctype in types.items():
+    if specmod.ELEM_SIZE[ctype] not in (1, 2, 4, 8):
+      raise NotFusable('element size of %s' % name)
+  insts = []
+  current = {}
+  for name in ins:
+    inst = Instance('in_%s' % name, name, 0, types[name])
+    insts.append(inst)
+    current[name] = inst
+  for it in range(depth):
+    for stage in spec['stages']:
+      inst = Instance('k%d_%s' % (it, stage['name']), stage['name'], it,
+                      stage['c_type'], stage)
+      for tensor, rel in stage['loads']:
+        inst.reads.append((current[tensor], tuple(rel), tensor))
+      insts.append(inst)
+      current[stage['name']] = inst
+    # output j feeds input j of the next iteration
+    for i, o in zip(ins, spec['outputs']):
+      if len(ins) == len(spec['outputs']):
+        current[i] = current[o]
+  final = current[spec['outputs'][0]]
+  final.final = True
+  # lags: a reader can produce row y once every row y+dy it reads exists;
+  # rows of loaded inputs count as existing `prefetch` steps after their load
+  for inst in insts:
+    if inst.stage is None:
+      inst.lag = 0
+      continue
+    inst.lag = max(src.lag + rel[1] + (prefetch if src.stage is None else 0)
+                   for src, rel, _ in inst.reads)
+  for inst in insts:
+    for src, rel, _ in inst.reads:
+      src.keep = max(src.keep, inst.lag - rel[1] - src.lag + 1)
+  for inst in insts:
+    if not inst.final and inst.keep == 0:
+      raise NotFusable('stage %s is never read' % inst.tensor)
+  return insts, final
+
+
+def geometry(spec, depth, cols, chunk_rows):
+  """Strip/chunk geometry for `depth` fused iterations."""
+  margins = specmod.iteration_margins(spec, depth)
+  if len(spec['inputs']) == 1 and len(spec['outputs']) == 1:
+    lo, hi = margins[-1]
+  else:
+    lo, hi = margins[0]
+  halo_lo = -(-lo[0] // cols) * cols      # padded up to whole vectors
+  halo_hi = -(-hi[0] // cols) * cols
+  w_out = LANES * cols - halo_lo - halo_hi
+  if w_out < cols:
+    raise NotFusable('depth %d leaves no output columns in a strip' % depth)
+  return dict(x_lo=lo[0], x_hi=hi[0], y_lo=lo[1], y_hi=hi[1],
+              halo_lo=halo_lo, halo_hi=halo_hi, w_out=w_out,
+              chunk_rows=chunk_rows)
+
+
+def kernel_name(spec, depth):
+  return '%s_fused_k%d' % (spec['app_name'], depth)
+
+
+def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
+         vgpr_budget=244):
+  """Returns (text, kernel table entry) for one fused depth."""
+  types = specmod.tensor_c_types(spec)
+  index = tensor_index(spec)
+  in_type = spec['inputs'][0]['c_type']
+  out_name = spec['outputs'][0]
+  elem = specmod.ELEM_SIZE[in_type]
+  if any(specmod.ELEM_SIZE[t['c_type']] != elem for t in spec['inputs']) or \
+      specmod.ELEM_SIZE[types[out_name]] != elem:
+    raise NotFusable('inputs and output of different widths')
+  if cols is None:
+    cols = max(1, 16 // elem)
+  insts, final = build_pipeline(spec, depth, prefetch)
+  geo = geometry(spec, depth, cols, chunk_rows)
+  for inst in insts:
+    for src, rel, _ in inst.reads:
+      if abs(rel[0]) > cols:
+        raise NotFusable('x offset %d exceeds the %d columns a lane holds'
+                         % (rel[0], cols))
+  period = 1
+  for inst in insts:
+    if inst.keep:
+      period = period * inst.keep // math.gcd(period, inst.keep)
+  if period > max_period:
+    raise NotFusable('rotation period %d too long' % period)
+  # register budget: every retained row costs C VGPRs per lane (2C for 8-byte
+  # types); past ~224 the kernel drops below two waves per SIMD and then spills
+  est_vgprs = sum(inst.keep * cols * max(1, specmod.ELEM_SIZE[inst.c_type] // 4)
+                  for inst in insts) + 4 * cols + 16
+  if est_vgprs > vgpr_budget:
+    raise NotFusable('depth %d would need about %d VGPRs (budget %d)'
+                     % (depth, est_vgprs, vgpr_budget))
+  name = kernel_name(spec, depth)
+  C = cols
+  L = final.lag
+  vec_bytes = C * elem
+  T_in = builtin_type(in_type)
+  T_out = builtin_type(types[out_name])
+
+  o = []
+  emit_line = o.append
+  emit_line('// fused depth-%d kernel: %d stage instance(s), rotation period %d,'
+            % (depth, len([i for i in insts if i.stage]), period))
+  emit_line('// strip = %d columns (%d out + halo %d/%d), chunk = %d rows, '
+            'prefetch %d rows'
+            % (LANES * C, geo['w_out'], geo['halo_lo'], geo['halo_hi'],
+               chunk_rows, prefetch))
+  emit_line('//   instance            lag keep')
+  for inst in insts:
+    emit_line('//   %-18s %4d %4d%s' % (inst.ident, inst.lag, inst.keep,
+                                        '  -> HBM' if inst.final else ''))
+  vec_in = 'vec_%s_in' % name
+  vec_out = 'vec_%s_out' % name
+  emit_line('typedef %s %s __attribute__((ext_vector_type(%d), aligned(%d)));'
+            % (T_in, vec_in, C, elem))
+  emit_line('typedef %s %s __attribute__((ext_vector_type(%d), aligned(%d)));'
+            % (T_out, vec_out, C, elem))
+  emit_line('template <bool INTERIOR>')
+  emit_line('DEV void %s_strip(const soda_hip_args& a, const i64 xs, const i64 x,'
+            ' const i64 y0, const i64 y1) {' % name)
+  emit_line('  const i64 W = a.dims[0], H = a.dims[1];')
+  emit_line('  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];')
+  emit_line('  const i64 st_hi = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];'
+            % (geo['w_out'], geo['w_out']))
+  for t in spec['inputs']:
+    emit_line('  const %s* __restrict__ g_%s = (const %s*)a.tensor[%d];' % (
+        builtin_type(t['c_type']), t['name'], builtin_type(t['c_type']),
+        index[t['name']]))
+  emit_line('  %s* __restrict__ g_out = (%s*)a.tensor[%d];' % (
+      T_out, T_out, index[out_name]))
+  for inst in insts:
+    if inst.keep:
+      emit_line('  %s %s[%d][%d];' % (builtin_type(inst.c_type), inst.ident,
+                                     inst.keep, C))
+  # windows start as zeros so that the prologue computes on defined values
+  for inst in insts:
+    for r in range(inst.keep):
+      emit_line('  ' + ' '.join('%s[%d][%d] = 0;' % (inst.ident, r, c)
+                                for c in range(C)))
+  emit_line('  // load head: first input row the chunk depends on')
+  emit_line('  i64 head = y0 - %d;' % geo['y_lo'])
+  emit_line('  const i64 steps = (y1 - y0) + %d;' % (L + geo['y_lo']))
+  emit_line('  for (i64 n = 0; n < steps; n += %d, head += %d) {' % (period, period))
+
+  def slot(inst, u, back):
+    """physical row of `inst`'s window holding its `back`-th newest row while
+    unrolled copy `u` runs (after `inst` produced this step's row)."""
+    return (u - back) % inst.keep
+
+  def operand(reader, src, rel, u, c):
+    back = reader.lag - src.lag - rel[1]
+    assert 0 <= back < src.keep, (reader.ident, src.ident, rel, back, src.keep)
+    row = '%s[%d]' % (src.ident, slot(src, u, back))
+    j = c + rel[0]
+    if 0 <= j < C:
+      return '%s[%d]' % (row, j)
+    if j < 0:
+      return 'from_lane_below(%s[%d])' % (row, C + j)
+    return 'from_lane_above(%s[%d])' % (row, j - C)
+
+  for u in range(period):
+    emit_line('    {  // unrolled step %d' % u)
+    for inst in insts:
+      if inst.stage is None:
+        s = slot(inst, u, 0)
+        emit_line('      {  // load row head+%d of %s' % (u, inst.tensor))
+        emit_line('        i64 row = head + %d; if (row > H - 1) row = H - 1;' % u)
+        emit_line('        const %s* p = g_%s + row * W + x;' % (
+            builtin_type(inst.c_type), inst.tensor))
+        emit_line('        if (INTERIOR) {')
+        emit_line('          const %s v = *(const %s*)p;' % (vec_in, vec_in))
+        for c in range(C):
+          emit_line('          %s[%d][%d] = v[%d];' % (inst.ident, s, c, c))
+        emit_line('        } else {')
+        for c in range(C):
+          emit_line('          %s[%d][%d] = (x + %d >= 0 && x + %d < W) ? p[%d] : '
+                    '(%s)0;' % (inst.ident, s, c, c, c, c,
+                                builtin_type(inst.c_type)))
+        emit_line('        }')
+        emit_line('      }')
+        continue
+      stage = inst.stage
+      ctype = builtin_type(inst.c_type)
+      by_name = {}
+      for src, rel, load_name in inst.reads:
+        by_name[(load_name, rel)] = src
+      if inst.final:
+        emit_line('      %s out_row[%d];' % (ctype, C))
+      for c in range(C):
+        def load(tensor, rel, u=u, c=c, inst=inst, by_name=by_name):
+          return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, c)
+        target = ('out_row[%d]' % c) if inst.final else \
+            '%s[%d][%d]' % (inst.ident, slot(inst, u, 0), c)
+        if stage['lets']:
+          emit_line('      {')
+          for let in stage['lets']:
+            emit_line('        const %s %s = %s;' % (
+                builtin_type(let['c_type']), let['name'],
+                specmod.substitute_loads(device_expr(let['expr']), load)))
+          emit_line('        %s = %s;' % (target, specmod.substitute_loads(
+              device_expr(stage['expr']), load)))
+          emit_line('      }')
+        else:
+          emit_line('      %s = %s;' % (target, specmod.substitute_loads(
+              device_expr(stage['expr']), load)))
+      if inst.final:
+        emit_line('      {  // store row head+%d-%d' % (u, L))
+        emit_line('        const i64 y = head + %d;' % (u - L))
+        emit_line('        if (y >= y0 && y < y1) {')
+        emit_line('          %s* q = g_out + y * W + x;' % T_out)
+        emit_line('          if (x >= st_lo && x + %d <= st_hi) {' % C)
+        emit_line('            %s v;' % vec_out)
+        for c in range(C):
+          emit_line('            v[%d] = out_row[%d];' % (c, c))
+        emit_line('            *(%s*)q = v;' % vec_out)
+        emit_line('          } else {')
+        for c in range(C):
+          emit_line('            if (x + %d >= st_lo && x + %d < st_hi) q[%d] = '
+                    'out_row[%d];' % (c, c, c, c))
+        emit_line('          }')
+        emit_line('        }')
+        emit_line('      }')
+    emit_line('    }')
+  emit_line('  }')
+  emit_line('}')
+  emit_line('')
+  emit_line('GLOBAL WG_SIZE(%d) void %s(soda_hip_args a) {'
+            % (WAVES_PER_BLOCK * LANES, name))
+  emit_line('  const int lane = lane_id();')
+  emit_line('  const int wave = __builtin_amdgcn_workitem_id_x() >> 6;')
+  emit_line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % C)
+  emit_line('  const i64 strip = (i64)__builtin_amdgcn_workgroup_id_x() * %d + wave;'
+            % WAVES_PER_BLOCK)
+  emit_line('  const i64 xs = x_origin + strip * %d;' % geo['w_out'])
+  emit_line('  if (xs >= a.box_hi[0]) return;')
+  emit_line('  const i64 x = xs - %d + lane * %d;' % (geo['halo_lo'], C))
+  emit_line('  const i64 y0 = a.box_lo[1] + (i64)__builtin_amdgcn_workgroup_id_y()'
+            ' * %d;' % chunk_rows)
+  emit_line('  const i64 y1 = y0 + %d < a.box_hi[1] ? y0 + %d : a.box_hi[1];'
+            % (chunk_rows, chunk_rows))
+  emit_line('  const bool interior = xs - %d >= 0 && xs - %d + %d <= a.dims[0];'
+            % (geo['halo_lo'], geo['halo_lo'], LANES * C))
+  emit_line('  if (interior) %s_strip<true>(a, xs, x, y0, y1);' % name)
+  emit_line('  else %s_strip<false>(a, xs, x, y0, y1);' % name)
+  emit_line('}')
+  entry = dict(name=name, kind='fused', depth=depth, stage=-1,
+               block=[WAVES_PER_BLOCK * LANES, 1, 1],
+               tile=[WAVES_PER_BLOCK * geo['w_out'] - C, chunk_rows, 1, 1],
+               cols=C, prefetch=prefetch, period=period, est_vgprs=est_vgprs,
+               halo=[geo['halo_lo'], geo['halo_hi']], w_out=geo['w_out'])
+  return '\n'.join(o) + '\n', entry

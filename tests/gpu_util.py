@@ -1,0 +1,47 @@
+"""Helpers of the GPU tests: programs are opened through the C ABI from the
+code objects that __graft_entry__.build() produced (or JIT-compiled from
+freshly generated kernel text when a test wants non-default generator options)."""
+import os
+
+import numpy as np
+
+from soda_hip import frontend
+from soda_hip.codegen import kernel
+from soda_hip.codegen import spec as specmod
+from soda_hip.runtime import host
+
+from conftest import ROOT, SAMPLES
+
+SEED = 20240607
+BLOBS = os.path.join(ROOT, 'soda-compiler_amd', 'blobs')
+
+
+def load_spec(app, **overrides):
+  st = frontend.load(os.path.join(SAMPLES, app + '.soda'), **overrides)
+  return specmod.spec_from_stencil(st)
+
+
+def open_prebuilt(app):
+  spec = load_spec(app)
+  path = os.path.join(BLOBS, app + '.hsaco')
+  assert os.path.exists(path), '%s missing: run __graft_entry__.build()' % path
+  return host.open_program(blob=path, spec=spec)
+
+
+def open_jit(app, iterate=None, **gen):
+  spec = load_spec(app, iterate=iterate) if iterate else load_spec(app)
+  text, _ = kernel.generate(spec, **gen)
+  return host.open_program(source=text, spec=spec)
+
+
+def random_inputs(spec, shape, seed=SEED, small_ints=False):
+  rng = np.random.default_rng(seed)
+  out = []
+  for t in spec['inputs']:
+    dt = np.dtype(specmod.NUMPY_NAME[t['c_type']])
+    if dt.kind == 'f':
+      out.append(rng.random(shape, dtype=np.float32).astype(dt))
+    else:
+      hi = 256 if small_ints else np.iinfo(dt).max + 1
+      out.append(rng.integers(0, hi, size=shape).astype(dt))
+  return out

@@ -1,0 +1,206 @@
+"""Parity of the HIP path against the CPU oracle and the reference fixtures.
+Everything here runs on a real MI355X and goes through libsoda_hip.so's C ABI.
+
+Bar: bit-exact for the integer programs AND for the float programs (the kernels
+evaluate the reference's expression text in the reference's order with FP
+contraction off, so there is nothing to round differently); the reference's own
+comparator (relative 1e-5, host.py:1124-1132) is checked through `<app>_test`.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from soda_hip.runtime import host
+from oracle import soda_oracle
+
+import gpu_util
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(GOLDEN, 'manifest.json')) as f:
+  MANIFEST = json.load(f)
+
+APPS = ('blur', 'jacobi2d', 'jacobi3d', 'seidel2d', 'heat3d', 'sobel2d',
+        'denoise2d', 'denoise3d')
+_PROGRAMS = {}
+_ORACLES = {}
+
+
+def program(app):
+  if app not in _PROGRAMS:
+    _PROGRAMS[app] = gpu_util.open_prebuilt(app)
+  return _PROGRAMS[app]
+
+
+def oracle(app):
+  if app not in _ORACLES:
+    _ORACLES[app] = soda_oracle.Oracle(gpu_util.load_spec(app))
+  return _ORACLES[app]
+
+
+def check(app, inputs, iterate, max_depth=0):
+  prog = program(app)
+  prog.set_max_depth(max_depth)
+  got = prog.run_numpy(inputs, iterate=iterate)
+  orc = oracle(app)
+  want = orc.run(inputs, iterate=iterate)
+  dims = tuple(reversed(inputs[0].shape))
+  sl = orc.valid_slices(dims, iterate)
+  for name, g in zip(prog.spec['outputs'], got):
+    w = want[name]
+    assert g[sl].size > 0
+    bad = np.argwhere(g[sl] != w[sl])
+    assert bad.size == 0, '%s %s it=%d depth=%d: %d cells differ, first at %s' % (
+        app, name, iterate, max_depth, len(bad), bad[0])
+  prog.set_max_depth(0)
+
+
+def test_device_is_gfx950():
+  assert host.device_count() >= 1
+  info = host.device_info(0)
+  assert info['arch'].startswith('gfx950'), info
+
+
+@pytest.mark.parametrize('fixture', sorted(
+    k for k in MANIFEST if k.endswith('.random.npz') or k.endswith('.ramp.npz')))
+def test_fixture(fixture):
+  """HIP result == what the reference's own CPU loop nest produced."""
+  meta = MANIFEST[fixture]
+  app, it = meta['key'].split('.iter')
+  it = int(it)
+  data = np.load(os.path.join(GOLDEN, fixture))
+  prog = program(app)
+  names = [t['name'] for t in prog.spec['inputs']]
+  if all('in_' + n in data for n in names):
+    inputs = [np.ascontiguousarray(data['in_' + n]) for n in names]
+  else:
+    inputs = host.reference_init(prog.spec, meta['dims'])
+  got = prog.run_numpy(inputs, iterate=it)
+  sl = oracle(app).valid_slices(tuple(meta['dims']), it)
+  for name, g in zip(prog.spec['outputs'], got):
+    want = data['out_' + name]
+    assert np.array_equal(g[sl], want[sl], equal_nan=True), (fixture, name)
+    # and the cells the reference never defines stay zero in the host protocol
+    assert np.array_equal(g, want, equal_nan=True), (fixture, name)
+
+
+@pytest.mark.parametrize('app', APPS)
+def test_random_vs_oracle_default_iterate(app):
+  spec = gpu_util.load_spec(app)
+  shape = (203, 517) if spec['dim'] == 2 else (37, 45, 70)
+  inputs = gpu_util.random_inputs(spec, shape, small_ints=(app == 'sobel2d'))
+  check(app, inputs, spec['iterate'])
+
+
+@pytest.mark.parametrize('iterate,max_depth', [
+    (1, 0), (2, 0), (3, 0), (5, 0), (8, 0), (16, 0), (21, 0), (37, 0),
+    (7, 1), (7, 2), (9, 4), (20, 8), (6, -1)])
+def test_jacobi2d_iterations_and_depths(iterate, max_depth):
+  """Temporal blocking: any split of `iterate` into fused depths, and the
+  per-stage kernels (max_depth -1), give the same bits."""
+  spec = gpu_util.load_spec('jacobi2d')
+  inputs = gpu_util.random_inputs(spec, (300, 1100))
+  check('jacobi2d', inputs, iterate, max_depth)
+
+
+@pytest.mark.parametrize('shape', [
+    (64, 64), (65, 257), (100, 241), (257, 1021), (41, 2049), (600, 97)])
+def test_jacobi2d_ragged_shapes(shape):
+  """Widths that are not multiples of the vector width / strip width, heights
+  that are not multiples of the chunk."""
+  spec = gpu_util.load_spec('jacobi2d')
+  check('jacobi2d', gpu_util.random_inputs(spec, shape), 5)
+
+
+@pytest.mark.parametrize('app,iterate', [('blur', 1), ('blur', 3), ('seidel2d', 6),
+                                         ('sobel2d', 2)])
+@pytest.mark.parametrize('max_depth', [0, -1])
+def test_multistage_fused_vs_stage_kernels(app, iterate, max_depth):
+  spec = gpu_util.load_spec(app)
+  inputs = gpu_util.random_inputs(spec, (130, 1300), small_ints=(app == 'sobel2d'))
+  check(app, inputs, iterate, max_depth)
+
+
+def test_empty_valid_region_is_not_an_error():
+  """iterate so large that nothing is left: nothing launched, zeros back."""
+  spec = gpu_util.load_spec('jacobi2d')
+  inputs = gpu_util.random_inputs(spec, (20, 30))
+  got = program('jacobi2d').run_numpy(inputs, iterate=10)
+  assert not got[0].any()
+
+
+def test_cfg1_blur_2000x100_sha256():
+  """BASELINE config 1 through the GPU path: hash of the whole result array."""
+  import hashlib
+  meta = MANIFEST['blur.iter1.2000x100.ramp.npz']
+  prog = program('blur')
+  inputs = host.reference_init(prog.spec, [2000, 100])
+  got = prog.run_numpy(inputs, iterate=1)[0]
+  assert hashlib.sha256(got.tobytes()).hexdigest() == meta['sha256']['blur_y']
+
+
+def test_app_test_entry_point(capfd):
+  """The generated `<app>_test(blob, dims)`: PASS line, zero mismatches, the two
+  timing lines of the reference (host.py:796-800)."""
+  spec = gpu_util.load_spec('jacobi2d')
+  blob = os.path.join(gpu_util.BLOBS, 'jacobi2d.hsaco')
+  errors = host.app_test(spec, blob, [500, 300, 0, 0])
+  out, err = capfd.readouterr()
+  assert errors == 0
+  assert 'INFO: PASS!' in err
+  assert 'Kernel execution time:' in out and 'Kernel throughput:' in out
+  spec = gpu_util.load_spec('blur')
+  assert host.app_test(spec, os.path.join(gpu_util.BLOBS, 'blur.hsaco'),
+                       [2000, 100, 0, 0]) == 0
+
+
+def test_jit_path_matches_prebuilt():
+  """Kernel text compiled at run time by hiprtc == the hipcc-built blob."""
+  prog = gpu_util.open_jit('jacobi2d', iterate=4)
+  spec = prog.spec
+  inputs = gpu_util.random_inputs(spec, (150, 700))
+  got = prog.run_numpy(inputs, iterate=4)[0]
+  ref = program('jacobi2d').run_numpy(inputs, iterate=4)[0]
+  assert np.array_equal(got, ref)
+  prog.close()
+
+
+def test_wrong_blob_is_refused():
+  from soda_hip.runtime import capi
+  spec = gpu_util.load_spec('blur')
+  with pytest.raises(capi.SodaHipError) as e:
+    host.open_program(blob=os.path.join(gpu_util.BLOBS, 'jacobi2d.hsaco'), spec=spec)
+  assert e.value.code == -103
+
+
+def test_full_size_properties_jacobi2d_8192():
+  """BASELINE config 2 size (8192^2, 100 iterations): size-independent checks.
+  (a) a linear ramp is a fixed point of the averaging stencil up to rounding:
+      the reference's own test input, checked with the reference's comparator;
+  (b) depth-16 blocking and depth-1 launches agree bit for bit;
+  (c) a horizontal band of rows checked against the oracle run on a sub-grid
+      that contains the band's whole dependency cone."""
+  prog = program('jacobi2d')
+  n, it = 8192, 100
+  rng = np.random.default_rng(5)
+  a = rng.random((n, n), dtype=np.float32)
+  prog.set_max_depth(0)
+  deep = prog.run_numpy([a], iterate=it)[0]
+  prog.set_max_depth(1)
+  flat = prog.run_numpy([a], iterate=it)[0]
+  prog.set_max_depth(0)
+  assert np.array_equal(deep, flat)
+  assert deep[it:-it, it:-it].std() > 0
+  # (c) rows [4000, 4016) depend on input rows [3900, 4116)
+  sub = np.ascontiguousarray(a[3900:4116, :])
+  want = oracle('jacobi2d').run([sub], iterate=it)['t0']
+  assert np.array_equal(deep[4000:4016, it:-it], want[100:116, it:-it])
+  # (a)
+  ramp = host.reference_init(prog.spec, [n, n])
+  out = prog.run_numpy(ramp, iterate=it)[0]
+  inner = (slice(it, n - it), slice(it, n - it))
+  rel = np.abs(out[inner] - ramp[0][inner]) / np.abs(ramp[0][inner])
+  assert rel.max() < 1e-4
