@@ -25,7 +25,33 @@ DEFAULT_MAX_DEPTH = 16
 
 HIPCC_FLAGS = ['-x', 'hip', '--offload-arch=gfx950', '--cuda-device-only',
                '--no-gpu-bundle-output', '-O3', '-ffp-contract=off',
-               '-fno-slp-vectorize', '-std=c++17']
+               '-fno-slp-vectorize', '-fwrapv', '-std=c++17']
+
+
+def extra_flags(spec):
+  """Per-program compiler flags beyond HIPCC_FLAGS.
+
+  ROCm 7.2's DPP-combine pass miscompiles the fused kernels of programs with
+  8/16-bit elements (a wave-shift DPP mov folded into a 16-bit VALU op gives
+  wrong values once intermediates exceed 16 bits before truncation: sobel2d at
+  depth >= 2; found by the parity tests, -O0 and -amdgpu-dpp-combine=false are
+  both correct).  Those programs are compiled with the pass off; 32/64-bit
+  programs keep it (their fused DPP adds are verified bit-exact)."""
+  sizes = [specmod.ELEM_SIZE[t] for t in specmod.tensor_c_types(spec).values()]
+  if min(sizes) < 4:
+    return ['-mllvm', '-amdgpu-dpp-combine=false']
+  return []
+
+
+FLAGS_MARK = '// SODA-HIP-FLAGS:'
+
+
+def flags_from_text(text):
+  """Extra flags recorded in generated kernel text (for run-time compiles)."""
+  for line in text.splitlines()[:400]:
+    if line.startswith(FLAGS_MARK):
+      return line[len(FLAGS_MARK):].split()
+  return []
 
 
 def default_cols(spec):
@@ -53,6 +79,8 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
   """Returns (kernel text, kernel table)."""
   max_depth = DEFAULT_MAX_DEPTH if max_depth is None else max_depth
   parts = [kernel_common.prelude(spec, __version__)]
+  if extra_flags(spec):
+    parts.append('%s %s\n' % (FLAGS_MARK, ' '.join(extra_flags(spec))))
   wrappers = kernel_common.math_wrappers(kernel_common.used_functions(spec))
   if wrappers:
     parts.append('// math calls resolve as in the reference CPU path: C double '
@@ -86,8 +114,8 @@ def compile_to_code_object(text, out_path, hipcc=None, extra_flags=()):
     f.write(text)
     src = f.name
   try:
-    subprocess.check_call([hipcc] + HIPCC_FLAGS + list(extra_flags) +
-                          [src, '-o', out_path])
+    subprocess.check_call([hipcc] + HIPCC_FLAGS + flags_from_text(text) +
+                          list(extra_flags) + [src, '-o', out_path])
   finally:
     os.unlink(src)
   return out_path

@@ -114,9 +114,11 @@ PRELUDE = '''\
 // Generated by sodac (SODA HIP back end, soda_hip %(version)s) for gfx950.
 // kernel: %(app)s    program hash: %(hash)s
 // Compile: hipcc -x hip --offload-arch=gfx950 --cuda-device-only \\
-//          --no-gpu-bundle-output -O3 -ffp-contract=off -std=c++17
-// or hand this text to libsoda_hip.so (hiprtc).  -ffp-contract=off is part of
-// the contract: the arithmetic must not be fused.
+//          --no-gpu-bundle-output -O3 -ffp-contract=off -fno-slp-vectorize \\
+//          -fwrapv -std=c++17
+// or hand this text to libsoda_hip.so (hiprtc).  -ffp-contract=off and -fwrapv
+// are part of the contract: no fused multiply-add, and signed overflow wraps
+// as it does in the reference's g++-built CPU path.
 #define GLOBAL extern "C" __attribute__((global))
 #define DEV static __attribute__((device)) inline __attribute__((always_inline))
 #define WG_SIZE(n) __attribute__((amdgpu_flat_work_group_size(n, n)))

@@ -98,7 +98,9 @@ class Blob:
       return cls.from_source(f.read())
 
   @classmethod
-  def from_source(cls, text, arch=None, options=('-fno-slp-vectorize',)):
+  def from_source(cls, text, arch=None, options=('-fno-slp-vectorize', '-fwrapv')):
+    from ..codegen.kernel import flags_from_text
+    options = tuple(options) + tuple(flags_from_text(text))
     h = ctypes.c_void_p()
     opts = (ctypes.c_char_p * len(options))(*[o.encode() for o in options])
     capi.check(capi.lib().soda_hip_module_compile(
