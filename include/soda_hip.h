@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SODA_HIP_ABI_VERSION 1
+#define SODA_HIP_ABI_VERSION 2
 #define SODA_HIP_MAX_DIMS 4
 #define SODA_HIP_MAX_TENSORS 16 /* inputs + stages of one program */
 #define SODA_HIP_MAX_IO 8
@@ -141,8 +141,13 @@ typedef struct soda_hip_kernel {
   int32_t depth;    /* FUSED: iterations advanced per launch */
   int32_t stage;    /* STAGE: tensor index produced */
   int32_t block[3]; /* workgroup shape */
-  int32_t tile[SODA_HIP_MAX_DIMS]; /* output cells one workgroup produces */
-  int32_t reserved[4];
+  int32_t tile[SODA_HIP_MAX_DIMS]; /* output cells one workgroup produces; for a
+                                      streaming kernel the outer-dimension entry
+                                      is only the default chunk length */
+  int32_t fill_rows; /* streaming kernels: extra outer-dimension rows a workgroup
+                        walks through before its first output row (pipeline
+                        fill + halo); 0 = not a streaming kernel */
+  int32_t reserved[3];
 } soda_hip_kernel;
 
 /* By-value argument of every generated kernel. */
@@ -151,6 +156,8 @@ typedef struct soda_hip_args {
   int64_t dims[SODA_HIP_MAX_DIMS];    /* array extents */
   int64_t box_lo[SODA_HIP_MAX_DIMS];  /* cells to produce: [box_lo, box_hi) */
   int64_t box_hi[SODA_HIP_MAX_DIMS];
+  int64_t param[4]; /* param[0]: outer-dimension rows per workgroup, chosen per
+                       launch so that the grid fills the chip in whole rounds */
 } soda_hip_args;
 
 /* ---- plan -------------------------------------------------------------------

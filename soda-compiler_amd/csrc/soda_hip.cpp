@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -63,7 +64,9 @@ struct soda_hip_plan {
   soda_hip_program prog{};
   std::vector<soda_hip_kernel> kernels;
   std::vector<hipFunction_t> funcs;
+  std::vector<int> resident_blocks;  // per kernel: workgroups the chip holds at once
   int max_depth = 0;
+  int chunk_rows_override = 0;       // SODA_HIP_CHUNK_ROWS, for tuning
   // scratch: [0, n_outputs) ping-pong partner of the outputs,
   // then one per non-output stage (only used by per-stage kernels)
   std::vector<void*> scratch;
@@ -193,7 +196,29 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
     if (desc.tile[d] <= 0)
       return fail(SODA_HIP_ERR_INTERNAL, "kernel %s has tile[%d]=%d", desc.name, d,
                   desc.tile[d]);
-    const int64_t g = (extent + desc.tile[d] - 1) / desc.tile[d];
+    int64_t tile = desc.tile[d];
+    if (d == dim - 1 && desc.fill_rows > 0 && dim >= 2) {
+      // Streaming kernel: every workgroup walks `chunk + fill_rows` rows of the
+      // outer dimension.  Pick the chunk length that minimises
+      //   rounds(chunk) * (chunk + fill_rows),
+      // rounds = ceil(workgroups / workgroups resident on the chip): a grid
+      // that is 2.4 chip-fulls costs 3, so aim for whole rounds.
+      int64_t inner = 1;
+      for (int e = 0; e < dim - 1; ++e) inner *= out->grid[e];
+      const int64_t resident = std::max(1, plan->resident_blocks[k]);
+      int64_t best = tile, best_cost = -1;
+      for (int64_t chunk = 32; chunk <= std::max<int64_t>(32, std::min<int64_t>(extent, 4096));
+           chunk += 4) {
+        const int64_t blocks = inner * ((extent + chunk - 1) / chunk);
+        const int64_t rounds = (blocks + resident - 1) / resident;
+        const int64_t cost = rounds * (chunk + desc.fill_rows);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = chunk; }
+      }
+      if (plan->chunk_rows_override > 0) best = plan->chunk_rows_override;
+      tile = best;
+      out->args.param[0] = best;
+    }
+    const int64_t g = (extent + tile - 1) / tile;
     if (g > (d == 0 ? 2147483647LL : 65535LL))
       return fail(SODA_HIP_ERR_EXTENTS_TOO_LARGE,
                   "grid dimension %d of kernel %s would be %lld", d, desc.name,
@@ -613,6 +638,23 @@ int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* progra
       return fail(SODA_HIP_ERR_NO_KERNEL, "kernel `%s` is not in the blob: %s",
                   name.c_str(), hipGetErrorString(e));
     }
+    {
+      // occupancy of this kernel on this device (MI355X_MICROARCH.md, register
+      // files: 512 VGPRs per lane per SIMD, granule 8, at most 8 waves per SIMD)
+      int regs = 0, dev = 0, cus = 256;
+      (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, pl->funcs[k]);
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess &&
+          hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        cus = prop.multiProcessorCount;
+      const int alloc = std::max(8, (regs + 7) / 8 * 8);
+      const int waves_per_simd = std::max(1, std::min(8, 512 / alloc));
+      const int threads = pl->kernels[k].block[0] * pl->kernels[k].block[1] *
+                          pl->kernels[k].block[2];
+      const int waves_per_block = std::max(1, (threads + 63) / 64);
+      pl->resident_blocks.push_back(
+          std::max(1, cus * (4 * waves_per_simd / waves_per_block)));
+    }
     const soda_hip_kernel& d = pl->kernels[k];
     if (d.block[0] < 1 || d.block[1] < 1 || d.block[2] < 1 ||
         (int64_t)d.block[0] * d.block[1] * d.block[2] > 1024) {
@@ -620,6 +662,7 @@ int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* progra
       return fail(SODA_HIP_ERR_CONSTRAINT, "kernel %d has a bad block shape", k);
     }
   }
+  if (const char* env = getenv("SODA_HIP_CHUNK_ROWS")) pl->chunk_rows_override = atoi(env);
   *plan = pl;
   return 0;
 }

@@ -12,7 +12,7 @@ import re
 
 from . import spec as specmod
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # element types as builtin spellings (no <stdint.h> in the translation unit)
 BUILTIN_TYPE = {
@@ -130,6 +130,7 @@ struct soda_hip_args {
   i64 dims[4];
   i64 box_lo[4];
   i64 box_hi[4];
+  i64 param[4];
 };
 
 DEV int lane_id() {

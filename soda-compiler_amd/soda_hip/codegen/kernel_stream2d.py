@@ -125,7 +125,7 @@ def kernel_name(spec, depth):
 
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
-         vgpr_budget=244):
+         vgpr_budget=244, waves_per_eu=0):
   """Returns (text, kernel table entry) for one fused depth."""
   types = specmod.tensor_c_types(spec)
   index = tensor_index(spec)
@@ -291,8 +291,12 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
   emit_line('  }')
   emit_line('}')
   emit_line('')
-  emit_line('GLOBAL WG_SIZE(%d) void %s(soda_hip_args a) {'
-            % (WAVES_PER_BLOCK * LANES, name))
+  occupancy = ''
+  if waves_per_eu > 0:
+    occupancy = ' __attribute__((amdgpu_waves_per_eu(%d, %d)))' % (
+        waves_per_eu, waves_per_eu)
+  emit_line('GLOBAL WG_SIZE(%d)%s void %s(soda_hip_args a) {'
+            % (WAVES_PER_BLOCK * LANES, occupancy, name))
   emit_line('  const int lane = lane_id();')
   emit_line('  const int wave = __builtin_amdgcn_workitem_id_x() >> 6;')
   emit_line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % C)
@@ -301,10 +305,10 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
   emit_line('  const i64 xs = x_origin + strip * %d;' % geo['w_out'])
   emit_line('  if (xs >= a.box_hi[0]) return;')
   emit_line('  const i64 x = xs - %d + lane * %d;' % (geo['halo_lo'], C))
+  emit_line('  const i64 chunk = a.param[0] > 0 ? a.param[0] : %d;' % chunk_rows)
   emit_line('  const i64 y0 = a.box_lo[1] + (i64)__builtin_amdgcn_workgroup_id_y()'
-            ' * %d;' % chunk_rows)
-  emit_line('  const i64 y1 = y0 + %d < a.box_hi[1] ? y0 + %d : a.box_hi[1];'
-            % (chunk_rows, chunk_rows))
+            ' * chunk;')
+  emit_line('  const i64 y1 = y0 + chunk < a.box_hi[1] ? y0 + chunk : a.box_hi[1];')
   emit_line('  const bool interior = xs - %d >= 0 && xs - %d + %d <= a.dims[0];'
             % (geo['halo_lo'], geo['halo_lo'], LANES * C))
   emit_line('  if (interior) %s_strip<true>(a, xs, x, y0, y1);' % name)
@@ -313,6 +317,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
   entry = dict(name=name, kind='fused', depth=depth, stage=-1,
                block=[WAVES_PER_BLOCK * LANES, 1, 1],
                tile=[WAVES_PER_BLOCK * geo['w_out'] - C, chunk_rows, 1, 1],
+               fill_rows=L + geo['y_lo'],
                cols=C, prefetch=prefetch, period=period, est_vgprs=est_vgprs,
                halo=[geo['halo_lo'], geo['halo_hi']], w_out=geo['w_out'])
   return '\n'.join(o) + '\n', entry

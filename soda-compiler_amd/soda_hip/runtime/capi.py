@@ -11,7 +11,7 @@ MAX_TENSORS = 16
 MAX_IO = 8
 MAX_WINDOWS = 64
 MAX_KERNELS = 32
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 KERNEL_STAGE = 0
 KERNEL_FUSED = 1
@@ -41,7 +41,7 @@ class KernelDesc(ctypes.Structure):
   _fields_ = [('name', ctypes.c_char * 96), ('kind', ctypes.c_int32),
               ('depth', ctypes.c_int32), ('stage', ctypes.c_int32),
               ('block', ctypes.c_int32 * 3), ('tile', ctypes.c_int32 * MAX_DIMS),
-              ('reserved', ctypes.c_int32 * 4)]
+              ('fill_rows', ctypes.c_int32), ('reserved', ctypes.c_int32 * 3)]
 
 
 class Timing(ctypes.Structure):

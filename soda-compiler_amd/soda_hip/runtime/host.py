@@ -177,6 +177,7 @@ def kernel_descs(table):
       d.block[i] = k['block'][i]
     for i in range(4):
       d.tile[i] = k['tile'][i]
+    d.fill_rows = k.get('fill_rows', 0)
   return arr
 
 

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Times single launches of fused-kernel variants on the GPU box.
+usage: tune.py app N iterate 'depth,cols,chunk_rows,prefetch' ...
+"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd'), os.path.join(ROOT, 'tests')]
+import numpy as np
+from soda_hip import frontend
+from soda_hip.codegen import kernel, spec as specmod
+from soda_hip.runtime import host
+
+app, n, iterate = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+st = frontend.load(os.path.join(ROOT, 'tests', 'samples', app + '.soda'), iterate=iterate)
+spec = specmod.spec_from_stencil(st)
+dims = [n, n]
+rng = np.random.default_rng(1)
+a = rng.random((n, n), dtype=np.float32)
+din = host.DeviceArray(a.nbytes); din.upload(a)
+dout = host.DeviceArray(a.nbytes); dout.zero()
+for variant in sys.argv[4:]:
+  parts = variant.split(',')
+  depth, cols, chunk, pf = [int(v) for v in parts[:4]]
+  extra = dict(kv.split('=') for kv in parts[4:])
+  extra = {k: int(v) for k, v in extra.items()}
+  t0 = time.time()
+  text, table = kernel.generate(spec, depths=[depth], cols=cols, chunk_rows=chunk, prefetch=pf, vgpr_budget=400, **extra)
+  try:
+    prog = host.open_program(source=text, spec=spec)
+  except Exception as e:
+    print(variant, 'FAILED', str(e)[:300]); continue
+  tc = time.time() - t0
+  t = prog.sweep_timed([din.ptr], [dout.ptr], dims, iterate, warmup=6, repeats=6)
+  valid = specmod.valid_cells(spec, dims, iterate)
+  print('%-28s compile %.1fs  %8.1f us/sweep  %d launches  dominant %s %.1f us  -> %.0f Gcell/s valid (%.0f nominal)' % (
+      variant, tc, t['kernel_us'], t['launches'], t['dominant_name'], t['dominant_us'] / t['dominant_launches'],
+      valid / t['kernel_us'] / 1e3, n * n * iterate / t['kernel_us'] / 1e3), flush=True)
+  prog.close(); prog.blob.unload()
