@@ -49,6 +49,8 @@ def parse_args():
                   help='iterations between halo exchanges (0 = auto)')
   ap.add_argument('--cpu-seconds', type=float, default=12.0,
                   help='CPU baseline sample budget (0 = skip)')
+  ap.add_argument('--force-dist', action='store_true',
+                  help='take the torch.distributed slab path even with 1 rank')
   ap.add_argument('--jit', action='store_true',
                   help='compile the kernels with hiprtc instead of loading the '
                        'code object built by __graft_entry__.build()')
@@ -105,6 +107,21 @@ def cpu_baseline(spec, dims, budget_s):
                      'OpenMP over all host cores, g++ -O3 -march=native '
                      '-ffp-contract=off; %.2f s' % (
                          n, 'x'.join(map(str, dims)), n + 2, t))
+
+
+def measured_traffic(kernel):
+  """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC
+  pass of this same command (profiles/rNN_traffic.json; tools/collect_profiles.py
+  explains the gfx950 correction).  PMC counters cannot be collected from inside
+  the timed process, so the figure comes from that separate run."""
+  import glob
+  files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
+  for path in reversed(files):
+    with open(path) as f:
+      data = json.load(f)
+    if kernel in data:
+      return data[kernel]['hbm_bytes_per_launch'], os.path.basename(path)
+  return None, None
 
 
 def launch_updates(spec, dims, iterate, depths):
@@ -193,7 +210,9 @@ def run_single(args):
                   effective_GBps=valid * abytes / (wall / args.steps) / 1e9,
                   device=host.device_info(0)['arch']),
       roofline=dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS,
-                    unit='GB/s', frac=achieved / HBM_PEAK_GBPS, traffic=None,
+                    unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
+                    traffic=measured_traffic(timing['dominant_name'])[0],
+                    traffic_source=measured_traffic(timing['dominant_name'])[1],
                     kernel=timing['dominant_name'],
                     kernel_avg_us=dom_avg_s * 1e6,
                     kernel_launches=timing['dominant_launches'],
@@ -210,7 +229,7 @@ def run_single(args):
 def main():
   args = parse_args()
   world = int(os.environ.get('WORLD_SIZE', '1'))
-  if args.gpus > 1 or world > 1:
+  if args.gpus > 1 or world > 1 or args.force_dist:
     from soda_hip.runtime import dist
     result = dist.bench_main(args, open_program, make_input, cpu_baseline,
                              launch_updates, depth_schedule, HBM_PEAK_GBPS)

@@ -1,0 +1,262 @@
+"""Multi-GPU execution: one process per GPU, the grid cut into slabs along the
+outermost (last, streamed) dimension, ghost rows exchanged between neighbours.
+
+The reference has nothing distributed (single FPGA), so
+this layer is new.  What it must preserve is the reference's semantics: no
+boundary condition, the valid box shrinks by the stencil window every iteration
+(reference core.py:794-835, host.py:1082-1091).  That makes the chain of slabs
+OPEN: the first and last rank have one neighbour, nothing wraps around.
+
+Per super-step of E iterations a rank
+  1. sends its first E*r_hi own rows down and its last E*r_lo own rows up, and
+     receives its neighbours' into its ghost rows  (one batched isend/irecv
+     pair per neighbour: RCCL over xGMI on GPUs, gloo in the CPU tests);
+  2. advances its slab E iterations in place of one: the sweep is told that the
+     ghost sides are fully valid (`valid_lo/hi = 0` there) and that the global
+     sides carry the margin of the iterations done so far, so after the sweep
+     exactly the rank's own rows are defined again.
+Halo cells are recomputed instead of exchanged inside a super-step, which trades
+`E*r` redundant rows per side for E times fewer (latency-bound) exchanges.
+
+The sweep itself is an injected `engine` (the HIP program in production; the
+tests inject a CPU engine built on the oracle to exercise this logic under
+gloo without a GPU).
+"""
+import os
+import time
+
+import numpy as np
+
+
+def slab_bounds(extent, world):
+  """Own rows [start, stop) of every rank: as even as possible."""
+  base, extra = divmod(extent, world)
+  out, start = [], 0
+  for r in range(world):
+    stop = start + base + (1 if r < extra else 0)
+    out.append((start, stop))
+    start = stop
+  return out
+
+
+class SlabPlan:
+  """Geometry of one rank's slab for a program with per-iteration radius
+  (r_lo, r_hi) along the last dimension."""
+
+  def __init__(self, dims, rank, world, r_lo, r_hi, exchange):
+    self.dims = list(dims)
+    self.rank, self.world = rank, world
+    self.r_lo, self.r_hi = r_lo, r_hi
+    bounds = slab_bounds(dims[-1], world)
+    self.start, self.stop = bounds[rank]
+    self.own = self.stop - self.start
+    self.has_lo = rank > 0
+    self.has_hi = rank < world - 1
+    smallest = min(b - a for a, b in bounds)
+    reach = max(r_lo, r_hi, 1)
+    # a ghost region cannot be deeper than the neighbour's own rows
+    self.exchange = max(1, min(exchange, smallest // reach)) if world > 1 else exchange
+    self.ghost_lo = self.exchange * r_lo if self.has_lo else 0
+    self.ghost_hi = self.exchange * r_hi if self.has_hi else 0
+    self.local_extent = self.ghost_lo + self.own + self.ghost_hi
+    self.local_dims = self.dims[:-1] + [self.local_extent]
+    # rows the neighbours need from us
+    self.send_up = self.exchange * r_lo if self.has_hi else 0    # our last rows
+    self.send_down = self.exchange * r_hi if self.has_lo else 0  # our first rows
+
+  def valid_margins(self, done, margins_of):
+    """valid_lo/valid_hi of the slab's input after `done` iterations, given
+    `margins_of(k)` -> (lo, hi) tuples of the global margins after k iterations."""
+    lo, hi = margins_of(done)
+    lo, hi = list(lo), list(hi)
+    if self.has_lo:
+      lo[-1] = 0
+    else:
+      lo[-1] = lo[-1]          # global edge: rows [0, margin) are undefined
+    if self.has_hi:
+      hi[-1] = 0
+    return lo, hi
+
+
+def exchange_ghosts(array, plan, dist, backend_ops=None):
+  """array: torch tensor of shape reversed(local_dims) (outer dim first).
+  Fills the ghost rows from the neighbours' own rows."""
+  if plan.world == 1:
+    return
+  ops = []
+  g_lo, g_hi, own = plan.ghost_lo, plan.ghost_hi, plan.own
+  first_own = g_lo
+  last_own = g_lo + own
+  if plan.has_lo:
+    # lower neighbour: it needs our first send_down rows, we need its last rows
+    ops.append(dist.P2POp(dist.isend, array[first_own:first_own + plan.send_down],
+                          plan.rank - 1))
+    ops.append(dist.P2POp(dist.irecv, array[0:g_lo], plan.rank - 1))
+  if plan.has_hi:
+    ops.append(dist.P2POp(dist.isend, array[last_own - plan.send_up:last_own],
+                          plan.rank + 1))
+    ops.append(dist.P2POp(dist.irecv, array[last_own:last_own + g_hi],
+                          plan.rank + 1))
+  if ops:
+    for req in dist.batch_isend_irecv(ops):
+      req.wait()
+
+
+def run_slab(engine, plan, arrays, iterate, margins_of, dist, depth_multiple=1):
+  """Advances the slab `iterate` iterations.  `arrays` = [A, B, C]: A holds the
+  level-0 slab (own rows filled, ghost rows anything) and is not written; the
+  result ends up in the returned array (B or C).  Returns (array, exchanges)."""
+  a, b, c = arrays
+  src, done, exchanges = a, 0, 0
+  dst_cycle = [b, c]
+  k = 0
+  while done < iterate:
+    exchange_ghosts(src, plan, dist)
+    exchanges += 1
+    step = min(plan.exchange, iterate - done)
+    lo, hi = plan.valid_margins(done, margins_of)
+    dst = dst_cycle[k % 2]
+    engine.sweep(src, dst, plan.local_dims, step, lo, hi)
+    src = dst
+    done += step
+    k += 1
+  return src, exchanges
+
+
+def auto_exchange(own_rows, reach, deepest, iterate):
+  """Iterations between exchanges: a multiple of the deepest fused kernel,
+  about four of them, but never more ghost rows than ~6% of the slab."""
+  e = deepest * 4
+  while e > deepest and e * reach * 2 > max(1, own_rows) * 0.12:
+    e -= deepest
+  return max(1, min(e, iterate))
+
+
+# ---------------------------------------------------------------------------
+# the HIP engine + bench driver (GPU only)
+# ---------------------------------------------------------------------------
+class HipEngine:
+  """Runs the sweep of a `host.Program` on torch CUDA tensors, on torch's
+  current stream so that it is ordered with RCCL traffic."""
+
+  def __init__(self, program, torch):
+    self.program, self.torch = program, torch
+
+  def sweep(self, src, dst, local_dims, iterations, valid_lo, valid_hi):
+    stream = self.torch.cuda.current_stream().cuda_stream
+    self.program.sweep([src.data_ptr()], [dst.data_ptr()], local_dims, iterations,
+                       valid_lo, valid_hi, stream=stream)
+
+
+def bench_main(args, open_program, make_input, cpu_baseline, launch_updates,
+               depth_schedule, hbm_peak):
+  """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`."""
+  import torch
+  import torch.distributed as dist
+  from . import capi, host
+  from ..codegen import spec as specmod
+
+  rank = int(os.environ.get('RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
+  torch.cuda.set_device(local_rank)
+  capi.check(capi.lib().soda_hip_set_device(local_rank))
+  dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+  try:
+    program, spec = open_program(args.app, args.iterate, args.jit)
+    program.set_max_depth(args.max_depth)
+    if len(spec['inputs']) != 1 or len(spec['outputs']) != 1:
+      raise SystemExit('multi-GPU bench handles one-input one-output programs')
+    dims = list(args.size)
+    r_lo, r_hi = spec['radius']['lo'][-1], spec['radius']['hi'][-1]
+    deepest = max([k['depth'] for k in program.kernels if k['kind'] == 'fused'
+                   and (args.max_depth <= 0 or k['depth'] <= args.max_depth)] or [1])
+    own_guess = dims[-1] // world
+    exchange = args.exchange or auto_exchange(own_guess, max(r_lo, r_hi, 1),
+                                              deepest, args.iterate)
+    plan = SlabPlan(dims, rank, world, r_lo, r_hi, exchange)
+    dt = program.in_dtypes[0]
+    tdt = {'float32': torch.float32, 'float64': torch.float64,
+           'uint16': torch.uint16, 'int16': torch.int16, 'uint8': torch.uint8,
+           'int32': torch.int32}[dt.name]
+    shape = tuple(reversed(plan.local_dims))
+    # the rank's slab of the global seeded input, plus room for ghosts
+    own = make_input(spec, dims, rows=(plan.start, plan.stop))[0]
+    dev = torch.device('cuda', local_rank)
+    a = torch.zeros(shape, dtype=tdt, device=dev)
+    a[plan.ghost_lo:plan.ghost_lo + plan.own].copy_(torch.from_numpy(own))
+    b = torch.zeros_like(a)
+    c = torch.zeros_like(a)
+    del own
+    engine = HipEngine(program, torch)
+    margin_table = specmod.iteration_margins(spec, args.iterate)
+
+    def margins_of(k):
+      if k == 0:
+        return (0,) * spec['dim'], (0,) * spec['dim']
+      return margin_table[k - 1]
+
+    def step():
+      return run_slab(engine, plan, [a, b, c], args.iterate, margins_of, dist)
+
+    for _ in range(args.warmup):
+      step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      _, exchanges = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                           device=dev)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    wall = float(elapsed.item())
+    result = None
+    if rank == 0:
+      valid = specmod.valid_cells(spec, dims, args.iterate)
+      nominal = int(np.prod(dims)) * args.iterate
+      per_step = wall / args.steps
+      abytes = specmod.algorithmic_bytes_per_update(spec)
+      # dominant kernel of THIS rank, timed per launch on its stream
+      seq = depth_schedule(program, min(plan.exchange, args.iterate), args.max_depth)
+      lo, hi = plan.valid_margins(0, margins_of)
+      timing = program.sweep_timed([a.data_ptr()], [b.data_ptr()], plan.local_dims,
+                                   min(plan.exchange, args.iterate), warmup=1,
+                                   repeats=3)
+      dom_avg_s = timing['dominant_us'] / max(1, timing['dominant_launches']) * 1e-6
+      dom_depth = max(seq)
+      local_cells = int(np.prod(plan.local_dims))
+      achieved = local_cells * dom_depth * abytes / dom_avg_s / 1e9
+      result = dict(
+          metric='gcell_updates_per_s', value=valid / per_step / 1e9,
+          unit='Gcell-updates/s', n_gpus=world, steps=args.steps,
+          warmup=args.warmup, ms_per_step=per_step * 1e3, higher_is_better=True,
+          scaling='strong', vs_baseline=None,
+          dtype='f32' if dt.kind == 'f' else 'u%d' % (8 * dt.itemsize),
+          data='synthetic',
+          config=dict(workload='%s.soda %s %s, iterate %d' % (
+              args.app, dt.name, 'x'.join(map(str, dims)), args.iterate),
+                      app=args.app, dims=dims, iterate=args.iterate,
+                      parallelism='outer-dim slabs x%d' % world,
+                      exchange_every=plan.exchange, exchanges_per_step=exchanges,
+                      ghost_rows=[plan.exchange * r_lo, plan.exchange * r_hi],
+                      valid_cell_updates=valid, nominal_cell_updates=nominal,
+                      nominal_gcell_updates_per_s=nominal / per_step / 1e9,
+                      effective_GBps=valid * abytes / per_step / 1e9,
+                      device=host.device_info(local_rank)['arch']),
+          roofline=dict(bound='hbm', achieved=achieved, peak=hbm_peak, unit='GB/s',
+                        frac=achieved / hbm_peak, traffic=None,
+                        kernel=timing['dominant_name'],
+                        kernel_avg_us=dom_avg_s * 1e6,
+                        kernel_launches=timing['dominant_launches'],
+                        algorithmic_bytes_per_update=abytes,
+                        updates_per_launch=local_cells * dom_depth,
+                        note='per-GPU figure for rank 0 (nominal cells of its '
+                             'slab incl. ghosts x depth)'))
+    program.close()
+    return result
+  finally:
+    dist.destroy_process_group()

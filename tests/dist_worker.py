@@ -1,0 +1,88 @@
+"""Worker of tests/test_dist.py: one rank of a gloo process group running the
+slab decomposition of soda_hip.runtime.dist with a CPU engine built on the
+oracle (test infrastructure; the product engine is the HIP program)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'soda-compiler_amd')):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+from soda_hip import frontend                      # noqa: E402
+from soda_hip.codegen import spec as specmod       # noqa: E402
+from soda_hip.runtime import dist as sdist         # noqa: E402
+from oracle import soda_oracle                     # noqa: E402
+
+
+class OracleEngine:
+  """sweep() with the same contract as libsoda_hip's soda_hip_sweep."""
+
+  def __init__(self, spec):
+    self.spec = spec
+    self.oracle = soda_oracle.Oracle(spec)
+
+  def sweep(self, src, dst, local_dims, iterations, valid_lo, valid_hi):
+    spec = self.spec
+    name_in = spec['inputs'][0]['name']
+    name_out = spec['outputs'][0]
+    cur = src.numpy()
+    boxes = soda_oracle.iteration_boxes(spec, iterations)
+    locals_ = {s['name']: np.zeros_like(cur, dtype=self.oracle.dtype(s['name']))
+               for s in spec['stages'] if s['name'] != name_out}
+    for k in range(iterations):
+      out = np.zeros_like(cur)
+      arrays = dict(locals_)
+      arrays[name_in] = cur
+      arrays[name_out] = out
+      shifted = {n: ([a - b for a, b in zip(lo, valid_lo)],
+                     [a + b for a, b in zip(hi, valid_hi)])
+                 for n, (lo, hi) in boxes[k].items()}
+      self.oracle._call(arrays, tuple(local_dims), shifted)
+      cur = out
+    dst.copy_(torch.from_numpy(cur))
+
+
+def main():
+  app, w, h, iterate, exchange, out_dir = sys.argv[1:7]
+  w, h, iterate, exchange = int(w), int(h), int(iterate), int(exchange)
+  rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+  dist.init_process_group(backend='gloo')
+  st = frontend.load(os.path.join(ROOT, 'tests', 'samples', app + '.soda'),
+                     iterate=iterate)
+  spec = specmod.spec_from_stencil(st)
+  dims = [w, h]
+  r_lo, r_hi = spec['radius']['lo'][-1], spec['radius']['hi'][-1]
+  plan = sdist.SlabPlan(dims, rank, world, r_lo, r_hi, exchange)
+  dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
+  rng = np.random.default_rng(99)
+  if dt.kind == 'f':
+    full = rng.random((h, w), dtype=np.float32).astype(dt)
+  else:
+    full = rng.integers(0, 65536, size=(h, w)).astype(dt)
+  shape = tuple(reversed(plan.local_dims))
+  a = torch.zeros(shape, dtype=torch.from_numpy(full[:1]).dtype)
+  a[plan.ghost_lo:plan.ghost_lo + plan.own] = torch.from_numpy(
+      full[plan.start:plan.stop])
+  b, c = torch.zeros_like(a), torch.zeros_like(a)
+  table = specmod.iteration_margins(spec, iterate)
+
+  def margins_of(k):
+    return ((0, 0), (0, 0)) if k == 0 else table[k - 1]
+
+  result, exchanges = sdist.run_slab(OracleEngine(spec), plan, [a, b, c], iterate,
+                                     margins_of, dist)
+  own = result[plan.ghost_lo:plan.ghost_lo + plan.own].numpy()
+  np.save(os.path.join(out_dir, 'rank%d.npy' % rank), own)
+  with open(os.path.join(out_dir, 'rank%d.txt' % rank), 'w') as f:
+    f.write('%d %d %d %d\n' % (plan.start, plan.stop, plan.exchange, exchanges))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,91 @@
+"""Multi-rank slab decomposition (soda_hip.runtime.dist) under gloo on the CPU:
+world sizes 2 and 3, exchange periods that do and do not divide the iteration
+count, symmetric and one-sided stencil windows."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from soda_hip import frontend
+from soda_hip.codegen import spec as specmod
+from soda_hip.runtime import dist as sdist
+from oracle import soda_oracle
+
+from conftest import ROOT, SAMPLES
+
+
+def free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def run_world(tmp_path, world, app, w, h, iterate, exchange):
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()),
+             WORLD_SIZE=str(world), OMP_NUM_THREADS='2')
+  procs = []
+  for rank in range(world):
+    procs.append(subprocess.Popen(
+        [sys.executable, os.path.join(ROOT, 'tests', 'dist_worker.py'), app,
+         str(w), str(h), str(iterate), str(exchange), str(tmp_path)],
+        env=dict(env, RANK=str(rank), LOCAL_RANK=str(rank))))
+  for p in procs:
+    assert p.wait(timeout=300) == 0
+  st = frontend.load(os.path.join(SAMPLES, app + '.soda'), iterate=iterate)
+  spec = specmod.spec_from_stencil(st)
+  dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
+  rng = np.random.default_rng(99)
+  if dt.kind == 'f':
+    full = rng.random((h, w), dtype=np.float32).astype(dt)
+  else:
+    full = rng.integers(0, 65536, size=(h, w)).astype(dt)
+  orc = soda_oracle.Oracle(spec)
+  want = orc.run([full], iterate=iterate)[spec['outputs'][0]]
+  sl = orc.valid_slices((w, h), iterate)
+  got = np.zeros_like(want)
+  meta = []
+  for rank in range(world):
+    start, stop, ex, n_ex = map(int, open(
+        os.path.join(tmp_path, 'rank%d.txt' % rank)).read().split())
+    got[start:stop] = np.load(os.path.join(tmp_path, 'rank%d.npy' % rank))
+    meta.append((start, stop, ex, n_ex))
+  assert want[sl].size > 0
+  assert np.array_equal(got[sl], want[sl])
+  return meta
+
+
+@pytest.mark.parametrize('world,app,w,h,iterate,exchange', [
+    (2, 'jacobi2d', 64, 50, 7, 3),
+    (2, 'jacobi2d', 40, 61, 6, 6),
+    (3, 'jacobi2d', 48, 47, 5, 2),
+    (2, 'seidel2d', 56, 40, 4, 2),
+    (2, 'blur', 70, 44, 3, 1),      # window reaches only towards higher indices
+    (3, 'blur', 70, 45, 4, 3),
+])
+def test_slabs_match_single_process(tmp_path, world, app, w, h, iterate, exchange):
+  meta = run_world(tmp_path, world, app, w, h, iterate, exchange)
+  assert meta[0][0] == 0 and meta[-1][1] == h
+  for (a0, a1, _, _), (b0, b1, _, _) in zip(meta, meta[1:]):
+    assert a1 == b0
+
+
+def test_slab_bounds_and_plan():
+  assert sdist.slab_bounds(10, 3) == [(0, 4), (4, 7), (7, 10)]
+  assert sdist.slab_bounds(16384, 8)[3] == (6144, 8192)
+  p = sdist.SlabPlan([16384, 16384], 3, 8, 1, 1, 48)
+  assert (p.ghost_lo, p.ghost_hi, p.own, p.local_extent) == (48, 48, 2048, 2144)
+  first = sdist.SlabPlan([16384, 16384], 0, 8, 1, 1, 48)
+  assert (first.ghost_lo, first.ghost_hi) == (0, 48)
+  # a ghost region can never exceed the neighbour's slab
+  tiny = sdist.SlabPlan([64, 20], 1, 4, 1, 1, 100)
+  assert tiny.exchange == 5 and tiny.ghost_lo == 5
+  # margins: neighbour sides are fully valid, global sides carry the margin
+  lo, hi = first.valid_margins(10, lambda k: ((k, k), (k, k)))
+  assert (lo, hi) == ([10, 10], [10, 0])
+  assert sdist.auto_exchange(2048, 1, 12, 1000) == 48
+  assert sdist.auto_exchange(64, 1, 12, 1000) == 12
