@@ -144,6 +144,8 @@ def launch_updates(spec, dims, iterate, depths):
 def depth_schedule(program, iterate, max_depth):
   depths = sorted({k['depth'] for k in program.kernels if k['kind'] == 'fused'
                    and (max_depth <= 0 or k['depth'] <= max_depth)}, reverse=True)
+  if not depths or max_depth < 0:   # per-stage kernels: one iteration per pass
+    return [1] * iterate
   seq, left = [], iterate
   while left > 0:
     k = next(d for d in depths if d <= left)

@@ -1,0 +1,161 @@
+"""Code generation on CPU: sodac CLI surface, printers, kernel text compiles for
+gfx950 (hipcc cross-compiles without a GPU), metadata round-trips."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from soda_hip import frontend
+from soda_hip.codegen import backend, kernel, kernel_common, kernel_stream2d
+from soda_hip.codegen import spec as specmod
+from soda_hip.runtime import host
+
+from conftest import ROOT, SAMPLES
+
+SODAC = os.path.join(ROOT, 'soda-compiler_amd', 'sodac')
+APPS = ('blur', 'jacobi2d', 'jacobi3d', 'seidel2d', 'heat3d', 'sobel2d',
+        'denoise2d', 'denoise3d')
+
+
+def spec_of(app, **kw):
+  return specmod.spec_from_stencil(
+      frontend.load(os.path.join(SAMPLES, app + '.soda'), **kw))
+
+
+def run_sodac(*argv, **kw):
+  return subprocess.run([sys.executable, SODAC] + list(argv), capture_output=True,
+                        text=True, **kw)
+
+
+def test_sodac_writes_all_artifacts(tmp_path):
+  r = run_sodac(os.path.join(SAMPLES, 'jacobi2d.soda'), '--hip-kernel',
+                str(tmp_path / 'k.hip'), '--hip-host', str(tmp_path / 'h.py'),
+                '--hip-header', str(tmp_path / 'h.h'), '--iterate', '12')
+  assert r.returncode == 0, r.stderr
+  text = (tmp_path / 'k.hip').read_text()
+  assert 'jacobi2d_fused_k12' in text and 'jacobi2d_stage_t0' in text
+  meta = kernel_common.read_meta_from_source(text)
+  assert meta['app_name'] == 'jacobi2d' and meta['abi'] == kernel_common.ABI_VERSION
+  assert meta['program_hash'] == kernel_common.program_hash(spec_of('jacobi2d'))
+  assert [k['depth'] for k in meta['kernels'] if k['kind'] == 'fused'] == \
+      [1, 2, 4, 8, 12]
+  shim = (tmp_path / 'h.py').read_text()
+  assert 'def jacobi2d(var_t1_buffer, var_t0_buffer, blob' in shim
+  assert 'def jacobi2d_test(blob, dims' in shim
+  compile(shim, 'h.py', 'exec')
+  header = (tmp_path / 'h.h').read_text()
+  assert 'int jacobi2d(buffer_t* var_t1_buffer, buffer_t* var_t0_buffer, ' \
+         'const char* blob)' in header
+  assert 'int jacobi2d_test(const char* blob, const int dims[4]);' in header
+  # the header is valid C
+  (tmp_path / 'x.c').write_text('#include "h.h"\nint main(void){return 0;}\n')
+  subprocess.check_call(['gcc', '-fsyntax-only', '-I', str(tmp_path),
+                         str(tmp_path / 'x.c')])
+
+
+def test_sodac_stdout_and_stdin():
+  with open(os.path.join(SAMPLES, 'blur.soda')) as f:
+    r = run_sodac('-', '--hip-kernel', '-', stdin=f)
+  assert r.returncode == 0
+  assert 'blur_fused_k1' in r.stdout and 'soda_hip_meta' in r.stdout
+
+
+def test_sodac_error_exit_codes(tmp_path):
+  bad = tmp_path / 'bad.soda'
+  bad.write_text('kernel: k\nburst width: 64\nunroll factor: 1\niterate: 1\n'
+                 'input float: a(8, *)\noutput float: b(0, 0) = a(0, 0) +\n')
+  r = run_sodac(str(bad), '--hip-kernel', '-')
+  assert r.returncode == 1 and 'syntax error' in r.stderr
+  r = run_sodac(os.path.join(SAMPLES, 'blur.soda'), '--iterate', '0',
+                '--hip-kernel', '-')
+  assert r.returncode == 1 and 'cannot iterate 0 times' in r.stderr
+  odd = tmp_path / 'odd.soda'
+  odd.write_text('kernel: k\nburst width: 64\nunroll factor: 1\niterate: 1\n'
+                 'input uint5: a(8, *)\noutput uint5: b(0, 0) = a(0, 0)\n')
+  r = run_sodac(str(odd), '--hip-kernel', '-')
+  assert r.returncode == 1 and 'no native GPU representation' in r.stderr
+
+
+def test_reference_flags_are_accepted():
+  r = run_sodac(os.path.join(SAMPLES, 'jacobi2d.soda'), '--burst-width', '256',
+                '--unroll-factor', '8', '--tile-size', '2000', '--dram-in', '1',
+                '--dram-out', '2', '--iterate', '3', '-v', '--hip-kernel', '-')
+  assert r.returncode == 0, r.stderr
+  meta = kernel_common.read_meta_from_source(r.stdout)
+  assert meta['spec']['iterate'] == 3 and meta['spec']['tile_size'] == [2000, 0]
+  assert meta['spec']['burst_width'] == 256
+
+
+@pytest.mark.parametrize('app', APPS)
+def test_every_sample_compiles_for_gfx950(app, tmp_path):
+  """The reference's only test pipes each sample through the kernel printer and
+  a syntax check (tests/test-compilation.sh); this is its HIP analogue, with a
+  real gfx950 compile."""
+  spec = spec_of(app, iterate=4 if app in ('jacobi2d', 'seidel2d') else None)
+  text, table = kernel.generate(spec, max_depth=4)
+  out = tmp_path / (app + '.hsaco')
+  kernel.compile_to_code_object(text, str(out))
+  assert out.stat().st_size > 1000
+  assert open(out, 'rb').read(4) == b'\x7fELF'
+  stages = [k for k in table if k['kind'] == 'stage']
+  assert len(stages) == len(spec['stages'])
+
+
+def test_pipeline_lags_match_the_reference_reuse_model():
+  """jacobi2d: each level trails the previous by one row and keeps three rows
+  (the reference's reuse chain for a 3-row window is 2 rows + 1)."""
+  spec = spec_of('jacobi2d', iterate=4)
+  insts, final = kernel_stream2d.build_pipeline(spec, 4, prefetch=3)
+  assert [i.lag for i in insts] == [0, 4, 5, 6, 7]
+  assert [i.keep for i in insts] == [6, 3, 3, 3, 0]
+  assert final.final and final.lag == 7
+  # blur: blur_x reads 3 input rows, blur_y only the current blur_x row
+  insts, final = kernel_stream2d.build_pipeline(spec_of('blur'), 1, prefetch=0)
+  assert [(i.ident, i.lag, i.keep) for i in insts] == \
+      [('in_input', 0, 3), ('k0_blur_x', 2, 1), ('k0_blur_y', 2, 0)]
+
+
+def test_unfusable_programs_fall_back_to_stage_kernels():
+  for app in ('jacobi3d', 'denoise2d'):
+    _, table = kernel.generate(spec_of(app))
+    assert all(k['kind'] == 'stage' for k in table) or app == 'denoise2d'
+  with pytest.raises(kernel_stream2d.NotFusable):
+    kernel_stream2d.emit(spec_of('jacobi3d'), 1)
+
+
+def test_narrow_types_disable_dpp_combine():
+  assert kernel.extra_flags(spec_of('blur')) == ['-mllvm',
+                                                 '-amdgpu-dpp-combine=false']
+  assert kernel.extra_flags(spec_of('jacobi2d')) == []
+  text, _ = kernel.generate(spec_of('sobel2d'))
+  assert kernel.flags_from_text(text) == ['-mllvm', '-amdgpu-dpp-combine=false']
+
+
+def test_program_desc_for_the_c_abi():
+  desc = host.program_desc(spec_of('sobel2d'))
+  assert (desc.dim, desc.n_inputs, desc.n_stages, desc.n_outputs) == (2, 1, 3, 1)
+  assert list(desc.elem_size[:4]) == [2, 2, 2, 2]
+  assert desc.output_tensor[0] == 3
+  wins = {(w.stage, w.parent): (list(w.lo[:2]), list(w.hi[:2]))
+          for w in desc.window[:desc.n_windows]}
+  assert wins[(1, 0)] == ([-1, -1], [1, 1])
+  assert wins[(3, 1)] == ([0, 0], [0, 0])
+
+
+def test_valid_cell_counts_match_survey():
+  """SURVEY.md section 8d work counts."""
+  spec = spec_of('jacobi2d')
+  def close(a, b):
+    return abs(a - b) <= 5e-4 * b
+  assert specmod.valid_cells(spec, [8192, 8192], 100) == \
+      sum((8192 - 2 * k) ** 2 for k in range(1, 101))
+  assert close(specmod.valid_cells(spec, [8192, 8192], 100), 6.547e9)
+  assert specmod.valid_cells(spec, [16384, 16384], 1000) == 236970022000
+  assert close(specmod.valid_cells(spec, [16384, 16384], 1000), 2.3697e11)
+  assert close(specmod.valid_cells(spec_of('jacobi3d'), [512, 512, 512], 200),
+               8.504e9)
+  assert specmod.valid_cells(spec_of('blur'), [16384, 16384], 1) == 268369924
+  assert specmod.algorithmic_bytes_per_update(spec) == 8
+  assert specmod.algorithmic_bytes_per_update(spec_of('blur')) == 4
