@@ -144,12 +144,28 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
       if abs(rel[0]) > cols:
         raise NotFusable('x offset %d exceeds the %d columns a lane holds'
                          % (rel[0], cols))
-  period = 1
-  for inst in insts:
-    if inst.keep:
-      period = period * inst.keep // math.gcd(period, inst.keep)
-  if period > max_period:
-    raise NotFusable('rotation period %d too long' % period)
+  # Rotation period: the row loop is unrolled `period` times so that every
+  # window's "shift" is a renaming; each keep must divide it.  Keeping MORE rows
+  # than needed is always legal, so keeps are rounded up to divisors of the
+  # period that costs the fewest registers (jacobi2d: 6,3,3.. -> period 6, no
+  # padding; denoise2d: 6,7,1,2,3.. would need lcm 42 -> period 8 with 8,8,1,2,4).
+  best = None
+  for candidate in range(1, max_period + 1):
+    if max(inst.keep for inst in insts) > candidate:
+      continue
+    divisors = [d for d in range(1, candidate + 1) if candidate % d == 0]
+    padded = [min(d for d in divisors if d >= inst.keep) if inst.keep else 0
+              for inst in insts]
+    cost = (sum(k * max(1, specmod.ELEM_SIZE[i.c_type] // 4)
+                for k, i in zip(padded, insts)), candidate)
+    if best is None or cost < best[0]:
+      best = (cost, candidate, padded)
+  if best is None:
+    raise NotFusable('windows of up to %d rows exceed the rotation period limit %d'
+                     % (max(inst.keep for inst in insts), max_period))
+  period = best[1]
+  for inst, keep in zip(insts, best[2]):
+    inst.keep = keep
   # register budget: every retained row costs C VGPRs per lane (2C for 8-byte
   # types); past ~224 the kernel drops below two waves per SIMD and then spills
   est_vgprs = sum(inst.keep * cols * max(1, specmod.ELEM_SIZE[inst.c_type] // 4)
