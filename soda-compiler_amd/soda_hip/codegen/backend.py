@@ -9,6 +9,8 @@ This module has the same two, with `--hip-*` flags where the Xilinx one has
   --hip-kernel FILE   HIP kernel text              (cf. --xocl-kernel)
   --hip-host FILE     Python host shim             (cf. --xocl-host)
   --hip-header FILE   C header                     (cf. --xocl-header)
+  --hip-host-cpp FILE C++ host defining `<app>` / `<app>_test` for C callers
+                      on top of libsoda_hip.so     (cf. --xocl-host)
   --hip-blob FILE     gfx950 code object, built by running hipcc on the kernel
                       text (cf. --xocl-hw-xo, which runs the Vivado tools)
   --hip [DIR]         all of the above under default names (cf. --xocl)
@@ -20,7 +22,7 @@ import logging
 import os
 import sys
 
-from . import header, host_shim, kernel
+from . import header, host_cpp, host_shim, kernel
 from . import spec as specmod
 
 _logger = logging.getLogger().getChild(__name__)
@@ -34,6 +36,8 @@ def add_arguments(parser):
                       metavar='file', help='HIP kernel code for gfx950')
   parser.add_argument('--hip-host', type=str, dest='hip_host_file',
                       metavar='file', help='Python host shim')
+  parser.add_argument('--hip-host-cpp', type=str, dest='hip_host_cpp_file',
+                      metavar='file', help='C++ host program over libsoda_hip.so')
   parser.add_argument('--hip-header', type=str, dest='hip_header_file',
                       metavar='file', help='C header of the entry points')
   parser.add_argument('--hip-blob', type=str, dest='hip_blob_file',
@@ -69,6 +73,7 @@ def print_code(stencil, args):
   files = dict(kernel=getattr(args, 'hip_kernel_file', None),
                host=getattr(args, 'hip_host_file', None),
                header=getattr(args, 'hip_header_file', None),
+               host_cpp=getattr(args, 'hip_host_cpp_file', None),
                blob=getattr(args, 'hip_blob_file', None))
   out_dir = getattr(args, 'hip_output_dir', None)
   if out_dir is not None:
@@ -76,15 +81,16 @@ def print_code(stencil, args):
       os.makedirs(out_dir)
     app = spec['app_name']
     defaults = dict(kernel='%s_kernel.hip' % app, host='%s.py' % app,
-                    header='%s.h' % app, blob='%s.hsaco' % app)
+                    header='%s.h' % app, blob='%s.hsaco' % app,
+                    host_cpp='%s_host.cpp' % app)
     for key, name in defaults.items():
       if files[key] is None:
         files[key] = os.path.join(out_dir, name)
   if not any(files.values()):
     return
-  text = None
-  if files['kernel'] or files['blob']:
-    text, _ = kernel.generate(
+  text = table = None
+  if files['kernel'] or files['blob'] or files['host_cpp']:
+    text, table = kernel.generate(
         spec, max_depth=max_depth, cols=getattr(args, 'hip_cols', None),
         chunk_rows=getattr(args, 'hip_chunk_rows', None))
   if files['kernel']:
@@ -103,6 +109,12 @@ def print_code(stencil, args):
     _logger.info('generate header as %s', files['header'])
     f, close = _open(files['header'])
     header.print_code(spec, f)
+    if close:
+      f.close()
+  if files['host_cpp']:
+    _logger.info('generate C++ host as %s', files['host_cpp'])
+    f, close = _open(files['host_cpp'])
+    host_cpp.print_code(spec, table, f)
     if close:
       f.close()
   if files['blob']:

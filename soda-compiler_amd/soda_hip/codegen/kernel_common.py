@@ -164,6 +164,16 @@ template <typename T, bool BELOW> DEV T lane_neighbour(T v) {
                                                        : dpp_from_above(w)));
   }
 }
+// the same exchange through the LDS crossbar (ds_bpermute_b32): no VALU issue
+// slot, but LDS-pipe latency that has to be covered by other work
+template <typename T, bool BELOW> DEV T lane_neighbour_bp(T v) {
+  static_assert(sizeof(T) == 4, "32-bit values only");
+  const int src = ((lane_id() + (BELOW ? -1 : 1)) & 63) << 2;
+  return __builtin_bit_cast(T, __builtin_amdgcn_ds_bpermute(
+      src, __builtin_bit_cast(int, v)));
+}
+template <typename T> DEV T from_lane_below_bp(T v) { return lane_neighbour_bp<T, true>(v); }
+template <typename T> DEV T from_lane_above_bp(T v) { return lane_neighbour_bp<T, false>(v); }
 template <typename T> DEV T from_lane_below(T v) { return lane_neighbour<T, true>(v); }
 template <typename T> DEV T from_lane_above(T v) { return lane_neighbour<T, false>(v); }
 '''

@@ -125,7 +125,7 @@ def kernel_name(spec, depth):
 
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
-         vgpr_budget=244, waves_per_eu=0):
+         vgpr_budget=244, waves_per_eu=0, bpermute=0):
   """Returns (text, kernel table entry) for one fused depth."""
   types = specmod.tensor_c_types(spec)
   index = tensor_index(spec)
@@ -237,9 +237,10 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
     j = c + rel[0]
     if 0 <= j < C:
       return '%s[%d]' % (row, j)
+    suffix = '_bp' if bpermute else ''
     if j < 0:
-      return 'from_lane_below(%s[%d])' % (row, C + j)
-    return 'from_lane_above(%s[%d])' % (row, j - C)
+      return 'from_lane_below%s(%s[%d])' % (suffix, row, C + j)
+    return 'from_lane_above%s(%s[%d])' % (suffix, row, j - C)
 
   for u in range(period):
     emit_line('    {  // unrolled step %d' % u)

@@ -159,3 +159,14 @@ def test_valid_cell_counts_match_survey():
   assert specmod.valid_cells(spec_of('blur'), [16384, 16384], 1) == 268369924
   assert specmod.algorithmic_bytes_per_update(spec) == 8
   assert specmod.algorithmic_bytes_per_update(spec_of('blur')) == 4
+
+
+@pytest.mark.parametrize('app', APPS)
+def test_generated_cpp_host_is_valid_cpp(app, tmp_path):
+  src = tmp_path / (app + '_host.cpp')
+  r = run_sodac(os.path.join(SAMPLES, app + '.soda'), '--hip-host-cpp', str(src))
+  assert r.returncode == 0, r.stderr
+  subprocess.check_call(['g++', '-std=c++11', '-fopenmp', '-fsyntax-only', '-Wall',
+                         '-Werror', '-I', os.path.join(ROOT, 'include'), str(src)])
+  text = src.read_text()
+  assert 'extern "C" int %s_test(const char* blob, const int dims[4])' % app in text

@@ -204,3 +204,37 @@ def test_full_size_properties_jacobi2d_8192():
   inner = (slice(it, n - it), slice(it, n - it))
   rel = np.abs(out[inner] - ramp[0][inner]) / np.abs(ramp[0][inner])
   assert rel.max() < 1e-4
+
+
+@pytest.mark.parametrize('app,dims,iterate', [
+    ('jacobi2d', [500, 300], '12'), ('blur', [2000, 100], '1'),
+    ('denoise2d', [300, 200], '1'), ('heat3d', [60, 50, 40], '3')])
+def test_generated_cpp_host_program(tmp_path, app, dims, iterate):
+  """`sodac --hip-host-cpp` output, built with g++ against include/soda_hip.h and
+  libsoda_hip.so and run as the reference README's test-bench: the C-caller form
+  of `<app>_test` (reference host.py:984-1167)."""
+  import subprocess
+  import sys
+  from conftest import ROOT
+  sodac = os.path.join(ROOT, 'soda-compiler_amd', 'sodac')
+  csrc = os.path.join(ROOT, 'soda-compiler_amd', 'csrc')
+  src = tmp_path / (app + '_host.cpp')
+  subprocess.check_call([sys.executable, sodac,
+                         os.path.join(ROOT, 'tests', 'samples', app + '.soda'),
+                         '--hip-host-cpp', str(src)])
+  exe = tmp_path / (app + '_host')
+  subprocess.check_call(['g++', '-std=c++11', '-O1', '-fopenmp', '-ffp-contract=off',
+                         '-DSODA_HIP_MAIN', '-I', os.path.join(ROOT, 'include'),
+                         str(src), '-L', csrc, '-lsoda_hip', '-Wl,-rpath,' + csrc,
+                         '-o', str(exe)])
+  blob = os.path.join(gpu_util.BLOBS, app + '.hsaco')
+  r = subprocess.run([str(exe), blob] + [str(d) for d in dims], capture_output=True,
+                     text=True, env=dict(os.environ, SODA_ITERATE=iterate))
+  assert r.returncode == 0, r.stderr
+  assert 'INFO: PASS!' in r.stderr
+  assert 'Kernel execution time:' in r.stdout
+  # a blob of another program is refused with the mismatch code, not run
+  other = os.path.join(gpu_util.BLOBS, 'seidel2d.hsaco')
+  r = subprocess.run([str(exe), other] + [str(d) for d in dims], capture_output=True,
+                     text=True)
+  assert r.returncode != 0 and 'not generated for this program' in r.stderr
