@@ -18,7 +18,7 @@ import subprocess
 import tempfile
 
 from .. import __version__
-from . import kernel_common, kernel_stage, kernel_stream2d
+from . import kernel_common, kernel_stage, kernel_stream2d, kernel_stream3d
 from . import spec as specmod
 
 DEFAULT_MAX_DEPTH = 12
@@ -98,6 +98,19 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
             spec, depth, cols=cols if cols else default_cols(spec),
             chunk_rows=chunk_rows or 256,
             prefetch=3 if prefetch is None else prefetch, **fused_options)
+      except kernel_stream2d.NotFusable as e:
+        notes.append('depth %d not fused: %s' % (depth, e))
+        continue
+      parts.append(ftext)
+      table.append(entry)
+  if fused and spec['dim'] == 3:
+    wanted3 = [d for d in (1, 2) if d <= max(1, spec['iterate'])] \
+        if len(spec['inputs']) == len(spec['outputs']) == 1 else [1]
+    if depths is not None:
+      wanted3 = sorted(set([1] + list(depths))) if len(wanted3) > 1 else [1]
+    for depth in wanted3:
+      try:
+        ftext, entry = kernel_stream3d.emit(spec, depth, **fused_options)
       except kernel_stream2d.NotFusable as e:
         notes.append('depth %d not fused: %s' % (depth, e))
         continue

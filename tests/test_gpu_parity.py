@@ -124,6 +124,17 @@ def test_multistage_fused_vs_stage_kernels(app, iterate, max_depth):
   check(app, inputs, iterate, max_depth)
 
 
+@pytest.mark.parametrize('app', ['jacobi3d', 'heat3d'])
+@pytest.mark.parametrize('shape,iterate,max_depth', [
+    ((70, 45, 37), 1, 0), ((70, 45, 37), 2, 0), ((40, 61, 130), 5, 0),
+    ((33, 29, 300), 4, 1), ((64, 64, 64), 3, -1), ((50, 33, 257), 6, 0)])
+def test_3d_fused_plane_streaming(app, shape, iterate, max_depth):
+  """2.5-D fused kernels (depth 1 and 2) against the oracle: tiles that overhang
+  the grid in x and y, z-chunks with remainders, odd iteration counts (2+2+1)."""
+  spec = gpu_util.load_spec(app)
+  check(app, gpu_util.random_inputs(spec, shape), iterate, max_depth)
+
+
 def test_empty_valid_region_is_not_an_error():
   """iterate so large that nothing is left: nothing launched, zeros back."""
   spec = gpu_util.load_spec('jacobi2d')
