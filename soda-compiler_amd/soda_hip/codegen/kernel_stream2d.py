@@ -125,7 +125,7 @@ def kernel_name(spec, depth):
 
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
-         vgpr_budget=244, waves_per_eu=0, bpermute=0):
+         vgpr_budget=244, waves_per_eu=0, bpermute=0, skip_fill=1):
   """Returns (text, kernel table entry) for one fused depth."""
   types = specmod.tensor_c_types(spec)
   index = tensor_index(spec)
@@ -173,6 +173,20 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
   if est_vgprs > vgpr_budget:
     raise NotFusable('depth %d would need about %d VGPRs (budget %d)'
                      % (depth, est_vgprs, vgpr_budget))
+  # First step at which each instance's row can matter.  Rows of the final
+  # output below the chunk's first row y0 are never stored, so walking back
+  # through the readers gives, per instance, how many rows below y0 it is still
+  # needed (`below`); it then first matters at step lag + y_lo - below.  During
+  # the pipeline fill the generated prologue skips instances before that step.
+  below = {id(final): 0}
+  for inst in reversed(insts):
+    need = below.get(id(inst))
+    if need is None:
+      continue
+    for src, rel, _ in inst.reads:
+      below[id(src)] = max(below.get(id(src), -10**9), need - rel[1])
+  for inst in insts:
+    inst.first_step = max(0, inst.lag + geo['y_lo'] - below.get(id(inst), 0))
   name = kernel_name(spec, depth)
   C = cols
   L = final.lag
@@ -223,7 +237,9 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
   emit_line('  // load head: first input row the chunk depends on')
   emit_line('  i64 head = y0 - %d;' % geo['y_lo'])
   emit_line('  const i64 steps = (y1 - y0) + %d;' % (L + geo['y_lo']))
-  emit_line('  for (i64 n = 0; n < steps; n += %d, head += %d) {' % (period, period))
+  prologue_steps = max(i.first_step for i in insts)
+  prologue_steps = -(-prologue_steps // period) * period if skip_fill else 0
+  emit_line('  i64 n = 0;')
 
   def slot(inst, u, back):
     """physical row of `inst`'s window holding its `back`-th newest row while
@@ -242,69 +258,84 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
       return 'from_lane_below%s(%s[%d])' % (suffix, row, C + j)
     return 'from_lane_above%s(%s[%d])' % (suffix, row, j - C)
 
-  for u in range(period):
-    emit_line('    {  // unrolled step %d' % u)
-    for inst in insts:
-      if inst.stage is None:
-        s = slot(inst, u, 0)
-        emit_line('      {  // load row head+%d of %s' % (u, inst.tensor))
-        emit_line('        i64 row = head + %d; if (row > H - 1) row = H - 1;' % u)
-        emit_line('        const %s* p = g_%s + row * W + x;' % (
-            builtin_type(inst.c_type), inst.tensor))
-        emit_line('        if (INTERIOR) {')
-        emit_line('          const %s v = *(const %s*)p;' % (vec_in, vec_in))
-        for c in range(C):
-          emit_line('          %s[%d][%d] = v[%d];' % (inst.ident, s, c, c))
-        emit_line('        } else {')
-        for c in range(C):
-          emit_line('          %s[%d][%d] = (x + %d >= 0 && x + %d < W) ? p[%d] : '
-                    '(%s)0;' % (inst.ident, s, c, c, c, c,
-                                builtin_type(inst.c_type)))
-        emit_line('        }')
-        emit_line('      }')
-        continue
-      stage = inst.stage
-      ctype = builtin_type(inst.c_type)
-      by_name = {}
-      for src, rel, load_name in inst.reads:
-        by_name[(load_name, rel)] = src
-      if inst.final:
-        emit_line('      %s out_row[%d];' % (ctype, C))
-      for c in range(C):
-        def load(tensor, rel, u=u, c=c, inst=inst, by_name=by_name):
-          return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, c)
-        target = ('out_row[%d]' % c) if inst.final else \
-            '%s[%d][%d]' % (inst.ident, slot(inst, u, 0), c)
-        if stage['lets']:
-          emit_line('      {')
-          for let in stage['lets']:
-            emit_line('        const %s %s = %s;' % (
-                builtin_type(let['c_type']), let['name'],
-                specmod.substitute_loads(device_expr(let['expr']), load)))
-          emit_line('        %s = %s;' % (target, specmod.substitute_loads(
-              device_expr(stage['expr']), load)))
+  def emit_body(guarded):
+    for u in range(period):
+      emit_line('    {  // unrolled step %d' % u)
+      for inst in insts:
+        if inst.stage is None:
+          s = slot(inst, u, 0)
+          emit_line('      {  // load row head+%d of %s' % (u, inst.tensor))
+          emit_line('        i64 row = head + %d; if (row > H - 1) row = H - 1;' % u)
+          emit_line('        const %s* p = g_%s + row * W + x;' % (
+              builtin_type(inst.c_type), inst.tensor))
+          emit_line('        if (INTERIOR) {')
+          emit_line('          const %s v = *(const %s*)p;' % (vec_in, vec_in))
+          for c in range(C):
+            emit_line('          %s[%d][%d] = v[%d];' % (inst.ident, s, c, c))
+          emit_line('        } else {')
+          for c in range(C):
+            emit_line('          %s[%d][%d] = (x + %d >= 0 && x + %d < W) ? p[%d] : '
+                      '(%s)0;' % (inst.ident, s, c, c, c, c,
+                                  builtin_type(inst.c_type)))
+          emit_line('        }')
           emit_line('      }')
-        else:
-          emit_line('      %s = %s;' % (target, specmod.substitute_loads(
-              device_expr(stage['expr']), load)))
-      if inst.final:
-        emit_line('      {  // store row head+%d-%d' % (u, L))
-        emit_line('        const i64 y = head + %d;' % (u - L))
-        emit_line('        if (y >= y0 && y < y1) {')
-        emit_line('          %s* q = g_out + y * W + x;' % T_out)
-        emit_line('          if (x >= st_lo && x + %d <= st_hi) {' % C)
-        emit_line('            %s v;' % vec_out)
+          continue
+        stage = inst.stage
+        ctype = builtin_type(inst.c_type)
+        skip = guarded and inst.first_step > u
+        if skip:
+          emit_line('      if (n + %d >= %d) {' % (u, inst.first_step))
+        by_name = {}
+        for src, rel, load_name in inst.reads:
+          by_name[(load_name, rel)] = src
+        if inst.final:
+          emit_line('      %s out_row[%d];' % (ctype, C))
         for c in range(C):
-          emit_line('            v[%d] = out_row[%d];' % (c, c))
-        emit_line('            *(%s*)q = v;' % vec_out)
-        emit_line('          } else {')
-        for c in range(C):
-          emit_line('            if (x + %d >= st_lo && x + %d < st_hi) q[%d] = '
-                    'out_row[%d];' % (c, c, c, c))
-        emit_line('          }')
-        emit_line('        }')
-        emit_line('      }')
-    emit_line('    }')
+          def load(tensor, rel, u=u, c=c, inst=inst, by_name=by_name):
+            return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, c)
+          target = ('out_row[%d]' % c) if inst.final else \
+              '%s[%d][%d]' % (inst.ident, slot(inst, u, 0), c)
+          if stage['lets']:
+            emit_line('      {')
+            for let in stage['lets']:
+              emit_line('        const %s %s = %s;' % (
+                  builtin_type(let['c_type']), let['name'],
+                  specmod.substitute_loads(device_expr(let['expr']), load)))
+            emit_line('        %s = %s;' % (target, specmod.substitute_loads(
+                device_expr(stage['expr']), load)))
+            emit_line('      }')
+          else:
+            emit_line('      %s = %s;' % (target, specmod.substitute_loads(
+                device_expr(stage['expr']), load)))
+        if inst.final:
+          emit_line('      {  // store row head+%d-%d' % (u, L))
+          emit_line('        const i64 y = head + %d;' % (u - L))
+          emit_line('        if (y >= y0 && y < y1) {')
+          emit_line('          %s* q = g_out + y * W + x;' % T_out)
+          emit_line('          if (x >= st_lo && x + %d <= st_hi) {' % C)
+          emit_line('            %s v;' % vec_out)
+          for c in range(C):
+            emit_line('            v[%d] = out_row[%d];' % (c, c))
+          emit_line('            *(%s*)q = v;' % vec_out)
+          emit_line('          } else {')
+          for c in range(C):
+            emit_line('            if (x + %d >= st_lo && x + %d < st_hi) q[%d] = '
+                      'out_row[%d];' % (c, c, c, c))
+          emit_line('          }')
+          emit_line('        }')
+          emit_line('      }')
+        if skip:
+          emit_line('      }')
+      emit_line('    }')
+
+  if prologue_steps:
+    emit_line('  // pipeline fill: instances start as their windows become useful')
+    emit_line('  for (; n < %d && n < steps; n += %d, head += %d) {'
+              % (prologue_steps, period, period))
+    emit_body(True)
+    emit_line('  }')
+  emit_line('  for (; n < steps; n += %d, head += %d) {' % (period, period))
+  emit_body(False)
   emit_line('  }')
   emit_line('}')
   emit_line('')

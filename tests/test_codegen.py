@@ -118,11 +118,29 @@ def test_pipeline_lags_match_the_reference_reuse_model():
 
 
 def test_unfusable_programs_fall_back_to_stage_kernels():
-  for app in ('jacobi3d', 'denoise2d'):
-    _, table = kernel.generate(spec_of(app))
-    assert all(k['kind'] == 'stage' for k in table) or app == 'denoise2d'
+  # eight stages of 3-D planes do not fit the register file: per-stage kernels
+  text, table = kernel.generate(spec_of('denoise3d'))
+  assert all(k['kind'] == 'stage' for k in table) and 'not fused' in text
   with pytest.raises(kernel_stream2d.NotFusable):
     kernel_stream2d.emit(spec_of('jacobi3d'), 1)
+  # 3-D single-output programs get the plane-streaming kernels
+  _, table = kernel.generate(spec_of('jacobi3d'))
+  fused = [k for k in table if k['kind'] == 'fused']
+  assert [k['depth'] for k in fused] == [1, 2]
+  assert fused[1]['tile'][1] == 12 and fused[1]['fill_rows'] == 4
+  # multi-input 2-D programs fuse at depth 1 with padded window lengths
+  _, table = kernel.generate(spec_of('denoise2d'))
+  assert [k['depth'] for k in table if k['kind'] == 'fused'] == [1]
+
+
+def test_fill_prologue_start_steps():
+  """During the pipeline fill level t of jacobi2d first matters at step
+  prefetch + 2t (it trails by t rows and is needed t rows further down)."""
+  spec = spec_of('jacobi2d', iterate=4)
+  text, entry = kernel_stream2d.emit(spec, 4, prefetch=3)
+  assert entry['fill_rows'] == 11
+  for t in (1, 2, 3, 4):
+    assert 'if (n + 0 >= %d) {' % (3 + 2 * t) in text
 
 
 def test_narrow_types_disable_dpp_combine():

@@ -10,12 +10,13 @@ from soda_hip import frontend
 from soda_hip.codegen import kernel, spec as specmod
 from soda_hip.runtime import host
 
-app, n, iterate = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+app, iterate = sys.argv[1], int(sys.argv[3])
+w, h = ([int(v) for v in sys.argv[2].split('x')] * 2)[:2]
 st = frontend.load(os.path.join(ROOT, 'tests', 'samples', app + '.soda'), iterate=iterate)
 spec = specmod.spec_from_stencil(st)
-dims = [n, n]
+dims = [w, h]
 rng = np.random.default_rng(1)
-a = rng.random((n, n), dtype=np.float32)
+a = rng.random((h, w), dtype=np.float32)
 din = host.DeviceArray(a.nbytes); din.upload(a)
 dout = host.DeviceArray(a.nbytes); dout.zero()
 for variant in sys.argv[4:]:
@@ -34,5 +35,5 @@ for variant in sys.argv[4:]:
   valid = specmod.valid_cells(spec, dims, iterate)
   print('%-28s compile %.1fs  %8.1f us/sweep  %d launches  dominant %s %.1f us  -> %.0f Gcell/s valid (%.0f nominal)' % (
       variant, tc, t['kernel_us'], t['launches'], t['dominant_name'], t['dominant_us'] / t['dominant_launches'],
-      valid / t['kernel_us'] / 1e3, n * n * iterate / t['kernel_us'] / 1e3), flush=True)
+      valid / t['kernel_us'] / 1e3, w * h * iterate / t['kernel_us'] / 1e3), flush=True)
   prog.close(); prog.blob.unload()
