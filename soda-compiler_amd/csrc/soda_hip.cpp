@@ -898,8 +898,10 @@ int soda_hip_run_buffers(soda_hip_plan* plan, soda_hip_buffer_t* const* inputs,
     const int es = p.elem_size[p.output_tensor[j]];
     int64_t lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1}, ext[3] = {1, 1, 1};
     bool empty = false;
+    // each output has its own composed window (host.py:1082-1091)
+    const Box& ob = plan->boxes[iterate - 1][p.output_tensor[j]];
     for (int d = 0; d < p.dim; ++d) {
-      lo[d] = mlo[d]; hi[d] = dims[d] - mhi[d]; ext[d] = dims[d];
+      lo[d] = -ob.lo[d]; hi[d] = dims[d] - ob.hi[d]; ext[d] = dims[d];
       if (hi[d] <= lo[d]) empty = true;
     }
     if (empty) continue;

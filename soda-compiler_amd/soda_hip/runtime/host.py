@@ -287,10 +287,13 @@ class Program:
     finally:
       for d in din + dout:
         d.free()
-    lo, hi = self.margins(iterate)
-    sl = tuple(slice(lo[d], dims[d] - hi[d]) for d in reversed(range(spec['dim'])))
+    # every output is defined on ITS OWN box (reference host.py:1082-1091)
+    boxes = specmod.iteration_boxes(spec, iterate)[-1]
     outs = []
-    for a in raw:
+    for name, a in zip(spec['outputs'], raw):
+      lo, hi = boxes[name]
+      sl = tuple(slice(-lo[d], dims[d] - hi[d])
+                 for d in reversed(range(spec['dim'])))
       clean = np.zeros_like(a)
       clean[sl] = a[sl]
       outs.append(clean)

@@ -249,3 +249,82 @@ def test_generated_cpp_host_program(tmp_path, app, dims, iterate):
   r = subprocess.run([str(exe), other] + [str(d) for d in dims], capture_output=True,
                      text=True)
   assert r.returncode != 0 and 'not generated for this program' in r.stderr
+
+
+def test_one_dimensional_program_jit():
+  """A 1-D program (the grammar's `name(*)` form): per-stage kernels, JIT path,
+  iterate 3, against the oracle."""
+  from soda_hip import frontend
+  from soda_hip.codegen import kernel
+  from soda_hip.codegen import spec as specmod
+  text = '''
+    kernel: smooth1d
+    burst width: 512
+    unroll factor: 1
+    iterate: 3
+    input float: a(*)
+    output float: b(0) = (a(-1) + a(0) * 2.0f + a(1)) * 0.25f
+  '''
+  spec = specmod.spec_from_stencil(frontend.loads(text))
+  assert spec['dim'] == 1
+  src, table = kernel.generate(spec)
+  prog = host.open_program(source=src, spec=spec)
+  a = np.random.default_rng(3).random((100003,), dtype=np.float32)
+  got = prog.run_numpy([a], iterate=3)[0]
+  orc = soda_oracle.Oracle(spec)
+  want = orc.run([a], iterate=3)['b']
+  assert np.array_equal(got[3:-3], want[3:-3])
+  assert got[3:-3].std() > 0
+  prog.close()
+
+
+def test_multi_output_program_uses_stage_kernels():
+  """Two outputs with different windows: each output is defined on its own box
+  (reference host.py:1082-1091); only the per-stage kernels can honour that."""
+  from soda_hip import frontend
+  from soda_hip.codegen import kernel
+  from soda_hip.codegen import spec as specmod
+  text = '''
+    kernel: two_out
+    burst width: 512
+    unroll factor: 1
+    iterate: 1
+    input float: a(64, *)
+    output float: sx(0, 0) = a(0, 0) + a(1, 0)
+    output float: sy(0, 0) = a(0, 0) - a(0, 3)
+  '''
+  spec = specmod.spec_from_stencil(frontend.loads(text))
+  src, table = kernel.generate(spec)
+  assert all(k['kind'] == 'stage' for k in table)
+  prog = host.open_program(source=src, spec=spec)
+  a = np.random.default_rng(4).random((70, 130), dtype=np.float32)
+  sx, sy = prog.run_numpy([a], iterate=1)
+  assert np.array_equal(sx[:, :-1], a[:, :-1] + a[:, 1:])
+  assert np.array_equal(sy[:-3, :], a[:-3, :] - a[3:, :])
+  prog.close()
+
+
+def test_multi_output_host_buffer_protocol():
+  """soda_hip_run_buffers writes back each output's own valid box."""
+  from soda_hip import frontend
+  from soda_hip.codegen import kernel
+  from soda_hip.codegen import spec as specmod
+  text = '''
+    kernel: two_out
+    burst width: 512
+    unroll factor: 1
+    iterate: 1
+    input float: a(64, *)
+    output float: sx(0, 0) = a(0, 0) + a(1, 0)
+    output float: sy(0, 0) = a(0, 0) - a(0, 3)
+  '''
+  spec = specmod.spec_from_stencil(frontend.loads(text))
+  src, _ = kernel.generate(spec)
+  prog = host.open_program(source=src, spec=spec)
+  a = np.random.default_rng(4).random((70, 130), dtype=np.float32)
+  sx = np.full_like(a, -1.0)
+  sy = np.full_like(a, -1.0)
+  prog.run_buffers([a], [sx, sy], 1)
+  assert np.array_equal(sx[:, :-1], a[:, :-1] + a[:, 1:]) and (sx[:, -1] == -1).all()
+  assert np.array_equal(sy[:-3, :], a[:-3, :] - a[3:, :]) and (sy[-3:, :] == -1).all()
+  prog.close()
