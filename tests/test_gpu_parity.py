@@ -377,3 +377,29 @@ def test_slab_decomposition_with_the_hip_engine(world, exchange, iterate):
   want = oracle('jacobi2d').run([full], iterate=iterate)['t0']
   sl = oracle('jacobi2d').valid_slices((w, h), iterate)
   assert np.array_equal(got[sl], want[sl])
+
+
+def test_denormals_signed_zeros_and_infinities():
+  """IEEE corner cases: subnormal inputs (no flush-to-zero on either side),
+  negative zeros, infinities (inf - inf = NaN must appear in the same cells)."""
+  rng = np.random.default_rng(21)
+  shape = (90, 700)
+  a = (rng.random(shape, dtype=np.float32) * np.float32(3e-39)).astype(np.float32)
+  a[rng.random(shape) < 0.05] = np.float32(-0.0)
+  a[10, 100] = np.inf
+  a[40, 300] = -np.inf
+  a[41, 300] = np.inf
+  assert (np.abs(a[np.isfinite(a)]) < np.finfo(np.float32).tiny).all()
+  prog = program('jacobi2d')
+  for it, depth in ((1, 0), (5, 0), (5, 1)):
+    prog.set_max_depth(depth)
+    got = prog.run_numpy([a], iterate=it)[0]
+    want = oracle('jacobi2d').run([a], iterate=it)['t0']
+    sl = oracle('jacobi2d').valid_slices((shape[1], shape[0]), it)
+    assert np.array_equal(np.isnan(got[sl]), np.isnan(want[sl]))
+    finite = ~np.isnan(want[sl])
+    # bit patterns, so that -0.0 vs +0.0 and subnormals are told apart
+    assert np.array_equal(got[sl][finite].view(np.uint32),
+                          want[sl][finite].view(np.uint32))
+    assert (got[sl][finite] != 0).any()
+  prog.set_max_depth(0)
