@@ -125,7 +125,7 @@ def kernel_name(spec, depth):
 
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
-         vgpr_budget=244, waves_per_eu=0, bpermute=0, skip_fill=1):
+         vgpr_budget=244, waves_per_eu=0, bpermute=0, skip_fill=1, xcd_remap=0):
   """Returns (text, kernel table entry) for one fused depth."""
   types = specmod.tensor_c_types(spec)
   index = tensor_index(spec)
@@ -348,14 +348,35 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
   emit_line('  const int lane = lane_id();')
   emit_line('  const int wave = __builtin_amdgcn_workitem_id_x() >> 6;')
   emit_line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % C)
-  emit_line('  const i64 strip = (i64)__builtin_amdgcn_workgroup_id_x() * %d + wave;'
-            % WAVES_PER_BLOCK)
+  if xcd_remap:
+    # Workgroups are dealt round-robin over the 8 XCDs (each with its own L2):
+    # ids b and b+8 share one.  Re-deal them so that every XCD works on a
+    # CONTIGUOUS run of tiles (x fastest): neighbouring strips and chunks, which
+    # re-read each other's halo columns / fill rows, then share an L2.  Pure
+    # speed; any placement is correct.  Bijective for any grid size.
+    # Measured on MI355X (jacobi2d 16384^2 k12/k8, blur k1): within +-1 %, blur
+    # -3 % -- the halo re-reads are a few percent of the traffic and the kernels
+    # are not L2-bound -- so it is OFF by default.
+    emit_line('  const unsigned gx = __builtin_amdgcn_grid_size_x() / %d;'
+              % (WAVES_PER_BLOCK * LANES))
+    emit_line('  const unsigned gy = __builtin_amdgcn_grid_size_y();')
+    emit_line('  const unsigned total = gx * gy;')
+    emit_line('  const unsigned lin = __builtin_amdgcn_workgroup_id_x() + gx * '
+              '__builtin_amdgcn_workgroup_id_y();')
+    emit_line('  const unsigned xcd = lin & 7u, within = lin >> 3;')
+    emit_line('  const unsigned share = total >> 3, extra = total & 7u;')
+    emit_line('  const unsigned tile_id = xcd * share + (xcd < extra ? xcd : extra) '
+              '+ within;')
+    emit_line('  const unsigned block_x = tile_id % gx, block_y = tile_id / gx;')
+  else:
+    emit_line('  const unsigned block_x = __builtin_amdgcn_workgroup_id_x();')
+    emit_line('  const unsigned block_y = __builtin_amdgcn_workgroup_id_y();')
+  emit_line('  const i64 strip = (i64)block_x * %d + wave;' % WAVES_PER_BLOCK)
   emit_line('  const i64 xs = x_origin + strip * %d;' % geo['w_out'])
   emit_line('  if (xs >= a.box_hi[0]) return;')
   emit_line('  const i64 x = xs - %d + lane * %d;' % (geo['halo_lo'], C))
   emit_line('  const i64 chunk = a.param[0] > 0 ? a.param[0] : %d;' % chunk_rows)
-  emit_line('  const i64 y0 = a.box_lo[1] + (i64)__builtin_amdgcn_workgroup_id_y()'
-            ' * chunk;')
+  emit_line('  const i64 y0 = a.box_lo[1] + (i64)block_y * chunk;')
   emit_line('  const i64 y1 = y0 + chunk < a.box_hi[1] ? y0 + chunk : a.box_hi[1];')
   emit_line('  const bool interior = xs - %d >= 0 && xs - %d + %d <= a.dims[0];'
             % (geo['halo_lo'], geo['halo_lo'], LANES * C))

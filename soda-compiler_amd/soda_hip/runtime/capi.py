@@ -126,6 +126,13 @@ def lib():
   global _LIB
   if _LIB is None:
     path = library_path()
+    if not os.path.exists(path) and not os.environ.get('SODA_HIP_LIB'):
+      # build on demand (the host compiler is enough: no device code inside)
+      import subprocess
+      try:
+        subprocess.check_call(['make', '-s', '-C', os.path.dirname(path)])
+      except (OSError, subprocess.CalledProcessError):
+        pass
     if not os.path.exists(path):
       raise SodaHipError(-19, 'no_device_interface',
                          '%s not found: build it with `make -C soda-compiler_amd/'
