@@ -125,7 +125,7 @@ def kernel_name(spec, depth):
 
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
-         vgpr_budget=244, waves_per_eu=0, bpermute=0, skip_fill=1, xcd_remap=0):
+         vgpr_budget=244, waves_per_eu=0, bpermute=0, skip_fill=1, xcd_remap=0, nontemporal=0):
   """Returns (text, kernel table entry) for one fused depth."""
   types = specmod.tensor_c_types(spec)
   index = tensor_index(spec)
@@ -269,7 +269,11 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
           emit_line('        const %s* p = g_%s + row * W + x;' % (
               builtin_type(inst.c_type), inst.tensor))
           emit_line('        if (INTERIOR) {')
-          emit_line('          const %s v = *(const %s*)p;' % (vec_in, vec_in))
+          if nontemporal:
+            emit_line('          const %s v = __builtin_nontemporal_load((const %s*)p);'
+                      % (vec_in, vec_in))
+          else:
+            emit_line('          const %s v = *(const %s*)p;' % (vec_in, vec_in))
           for c in range(C):
             emit_line('          %s[%d][%d] = v[%d];' % (inst.ident, s, c, c))
           emit_line('        } else {')
@@ -316,7 +320,10 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
           emit_line('            %s v;' % vec_out)
           for c in range(C):
             emit_line('            v[%d] = out_row[%d];' % (c, c))
-          emit_line('            *(%s*)q = v;' % vec_out)
+          if nontemporal:
+            emit_line('            __builtin_nontemporal_store(v, (%s*)q);' % vec_out)
+          else:
+            emit_line('            *(%s*)q = v;' % vec_out)
           emit_line('          } else {')
           for c in range(C):
             emit_line('            if (x + %d >= st_lo && x + %d < st_hi) q[%d] = '

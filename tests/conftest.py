@@ -3,6 +3,15 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm ships its own libamdhip64; whichever HIP runtime is loaded first
+# owns the process.  Import torch BEFORE libsoda_hip.so is loaded (bench.py and
+# the multi-GPU driver do the same) so that both use one runtime; the other
+# order leaves torch with "No HIP GPUs are available".
+try:
+  import torch  # noqa: F401
+except ImportError:   # CPU-only environments without torch still run the suite
+  torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'soda-compiler_amd')):
   if p not in sys.path:

@@ -1,0 +1,71 @@
+// Copy-kernel variants: what HBM rate can a streaming kernel reach on this box?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("ERR %s line %d: %s\n", #x, __LINE__, hipGetErrorString(e)); exit(1);} } while (0)
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+template <int NT_LD, int NT_ST, int UNROLL>
+__global__ void __launch_bounds__(256) copy_flat(const float4v* __restrict__ in, float4v* __restrict__ out, size_t n) {
+  size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x);
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+    float4v v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) v[u] = NT_LD ? __builtin_nontemporal_load(&in[i + u * stride]) : in[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) { if (NT_ST) __builtin_nontemporal_store(v[u], &out[i + u * stride]); else out[i + u * stride] = v[u]; }
+  }
+}
+
+// each wave walks down rows of a 2-D array: 1 KiB per row per wave, like the stencil kernels
+template <int NT_LD, int NT_ST, int PF>
+__global__ void __launch_bounds__(256) copy_rows(const float* __restrict__ in, float* __restrict__ out, long W, long H, long chunk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long x = ((long)blockIdx.x * 4 + wave) * 256 + lane * 4;
+  if (x >= W) return;
+  const long y0 = (long)blockIdx.y * chunk, y1 = y0 + chunk < H ? y0 + chunk : H;
+  float4v ring[PF];
+#pragma unroll
+  for (int p = 0; p < PF; ++p) { long y = y0 + p < H ? y0 + p : H - 1; const float4v* q = (const float4v*)(in + y * W + x); ring[p] = NT_LD ? __builtin_nontemporal_load(q) : *q; }
+  for (long y = y0; y < y1; y += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      float4v v = ring[p];
+      long yn = y + p + PF; if (yn > H - 1) yn = H - 1;
+      const float4v* q = (const float4v*)(in + yn * W + x);
+      ring[p] = NT_LD ? __builtin_nontemporal_load(q) : *q;
+      if (y + p < y1) { float4v* o = (float4v*)(out + (y + p) * W + x); if (NT_ST) __builtin_nontemporal_store(v, o); else *o = v; }
+    }
+  }
+}
+
+template <typename F> void timeit(const char* name, size_t bytes, F f) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  f(); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0)); for (int r = 0; r < 10; ++r) f(); CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("%-44s %.3f ms  %.2f TB/s (read+write)\n", name, ms / 10, 2.0 * bytes * 10 / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+  const long W = 16384, H = 16384; const size_t bytes = (size_t)W * H * 4, n = bytes / 16;
+  float *a, *b; CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 0, bytes));
+  const float4v* a4 = (const float4v*)a; float4v* b4 = (float4v*)b;
+  for (int blocks : {1024, 2048, 4096, 8192}) {
+    char nm[96];
+    snprintf(nm, sizeof nm, "flat plain u1 blocks=%d", blocks); timeit(nm, bytes, [&] { copy_flat<0,0,1><<<blocks,256>>>(a4, b4, n); });
+    snprintf(nm, sizeof nm, "flat plain u4 blocks=%d", blocks); timeit(nm, bytes, [&] { copy_flat<0,0,4><<<blocks,256>>>(a4, b4, n); });
+    snprintf(nm, sizeof nm, "flat nt-ld nt-st u4 blocks=%d", blocks); timeit(nm, bytes, [&] { copy_flat<1,1,4><<<blocks,256>>>(a4, b4, n); });
+    snprintf(nm, sizeof nm, "flat nt-st u4 blocks=%d", blocks); timeit(nm, bytes, [&] { copy_flat<0,1,4><<<blocks,256>>>(a4, b4, n); });
+  }
+  for (long chunk : {128L, 256L, 512L, 1024L}) {
+    dim3 grid((unsigned)(W / 1024), (unsigned)((H + chunk - 1) / chunk));
+    char nm[96];
+    snprintf(nm, sizeof nm, "rows plain pf3 chunk=%ld", chunk); timeit(nm, bytes, [&] { copy_rows<0,0,3><<<grid,256>>>(a, b, W, H, chunk); });
+    snprintf(nm, sizeof nm, "rows plain pf6 chunk=%ld", chunk); timeit(nm, bytes, [&] { copy_rows<0,0,6><<<grid,256>>>(a, b, W, H, chunk); });
+    snprintf(nm, sizeof nm, "rows nt-ld nt-st pf6 chunk=%ld", chunk); timeit(nm, bytes, [&] { copy_rows<1,1,6><<<grid,256>>>(a, b, W, H, chunk); });
+    snprintf(nm, sizeof nm, "rows nt-st pf6 chunk=%ld", chunk); timeit(nm, bytes, [&] { copy_rows<0,1,6><<<grid,256>>>(a, b, W, H, chunk); });
+  }
+  return 0;
+}
