@@ -188,3 +188,21 @@ def test_generated_cpp_host_is_valid_cpp(app, tmp_path):
                          '-Werror', '-I', os.path.join(ROOT, 'include'), str(src)])
   text = src.read_text()
   assert 'extern "C" int %s_test(const char* blob, const int dims[4])' % app in text
+
+
+@pytest.mark.parametrize('app', APPS)
+def test_compilation_sweep_like_the_reference_script(app, tmp_path):
+  """reference tests/test-compilation.sh:5-10 pipes every sample through
+  `sodac --xocl-kernel -` and a syntax-only compile, forwarding extra flags such
+  as --unroll-factor; the HIP analogue, through the real CLI and hipcc."""
+  iterates = ['1', '3'] if app not in ('denoise2d', 'denoise3d') else ['1']
+  for unroll, iterate in zip(('1', '4'), iterates + iterates):
+    r = run_sodac(os.path.join(SAMPLES, app + '.soda'), '--unroll-factor', unroll,
+                  '--iterate', iterate, '--hip-max-depth', '2', '--hip-kernel', '-')
+    assert r.returncode == 0, r.stderr
+    src = tmp_path / ('%s_u%s_i%s.hip' % (app, unroll, iterate))
+    src.write_text(r.stdout)
+    flags = [f for f in kernel.HIPCC_FLAGS if f != '--no-gpu-bundle-output']
+    subprocess.check_call(['/opt/rocm/bin/hipcc'] + flags +
+                          kernel.flags_from_text(r.stdout) +
+                          ['-fsyntax-only', str(src)])
