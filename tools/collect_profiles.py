@@ -26,11 +26,12 @@ def main():
   src = os.path.join(ROOT, 'gpurun_out')
   dst = os.path.join(ROOT, 'profiles')
   os.makedirs(dst, exist_ok=True)
-  stats = glob.glob(os.path.join(src, 'prof_%s' % tag, '*', '*_kernel_stats.csv'))[0]
+  newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)
+  stats = newest(os.path.join(src, 'prof_%s' % tag, '*', '*_kernel_stats.csv'))
   shutil.copy(stats, os.path.join(dst, '%s_kernel_stats.csv' % tag))
   traffic = {}
   for counter, folder in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
-    f = glob.glob(os.path.join(src, folder, '*', '*_counter_collection.csv'))[0]
+    f = newest(os.path.join(src, folder, '*', '*_counter_collection.csv'))
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
       if r['Counter_Name'] == counter:
