@@ -23,6 +23,141 @@ def _array(values):
   return '{%s}' % ', '.join(str(int(v)) for v in values)
 
 
+HEADERS = ('cassert cfloat cmath cstdbool cstddef cstdint cstdio cstdlib cstring '
+           'algorithm array string unordered_map').split()
+
+
+def print_prologue(out):
+  """Same system headers as the reference's host translation unit
+  (host.py:12-36): they decide which overload an unqualified `sqrt(float)` is
+  (the C `double sqrt(double)`)."""
+  for h in HEADERS:
+    out.write('#include <%s>\n' % h)
+  out.write('static FILE* const* error_report = &stderr;\n')
+
+
+def print_selfcheck(spec, out):
+  """`<app>_selfcheck`: the CPU half of `<app>_test` (reference
+  host.py:1073-1146): recompute `iterate` iterations with the plain loop nest,
+  compare the device outputs on the box the reference compares (exact for
+  integers, squared relative error for floats), report up to `max_report`
+  mismatches, return their count.  Reads the device result, never produces
+  one."""
+  app = spec['app_name']
+  dim = spec['dim']
+  types = specmod.tensor_c_types(spec)
+  index = tensor_index(spec)
+  ins = [t['name'] for t in spec['inputs']]
+  outs = list(spec['outputs'])
+  stages = spec['stages']
+  windows = []
+  for stage, wins in specmod.stage_windows(spec).items():
+    for parent, (lo, hi) in wins.items():
+      windows.append((index[stage], index[parent], lo, hi))
+  w = out.write
+  w('extern "C" long long %s_selfcheck(const void* const* inputs, '
+    'const void* const* device_outputs, const int dims[4], int iterate, '
+    'double threshold, int max_report) {\n' % app)
+  w('  long long error_count = 0;\n')
+  w('  (void)threshold; (void)max_report;\n')
+  w('  size_t cells = 1;\n  for (int d = 0; d < %d; ++d) cells *= (size_t)dims[d];\n'
+    % dim)
+  w('  const int64_t stride0 = 1; (void)stride0;\n')
+  for d in range(1, dim):
+    w('  const int64_t stride%d = %s;\n' % (d, ' * '.join(
+        '(int64_t)dims[%d]' % x for x in range(d))))
+  w('  static const int32_t win[][%d] = {%s};\n' % (2 + 2 * dim, ', '.join(
+      _array([st, pa] + list(lo) + list(hi)) for st, pa, lo, hi in windows)))
+  w('  int32_t box_lo[%d][%d], box_hi[%d][%d];  // per tensor, composed window\n'
+    % (len(index), dim, len(index), dim))
+  w('  memset(box_lo, 0, sizeof box_lo); memset(box_hi, 0, sizeof box_hi);\n')
+  for s in stages:
+    n = s['name']
+    for k in range(2 if n in outs else 1):
+      w('  %s* buf_%s_%d = new %s[cells]();\n' % (types[n], n, k, types[n]))
+  w('  for (int it = 0; it < iterate; ++it) {\n')
+  w('    const bool last = it == iterate - 1;\n')
+  w('    for (int s = %d; s < %d; ++s) {\n' % (len(ins), len(index)))
+  w('      bool first = true;\n')
+  w('      for (size_t k = 0; k < sizeof win / sizeof win[0]; ++k) {\n')
+  w('        if (win[k][0] != s) continue;\n')
+  w('        for (int d = 0; d < %d; ++d) {\n' % dim)
+  w('          const int32_t lo = box_lo[win[k][1]][d] + win[k][2 + d];\n')
+  w('          const int32_t hi = box_hi[win[k][1]][d] + win[k][%d + d];\n' % (2 + dim))
+  w('          box_lo[s][d] = first ? lo : std::min(box_lo[s][d], lo);\n')
+  w('          box_hi[s][d] = first ? hi : std::max(box_hi[s][d], hi);\n')
+  w('        }\n        first = false;\n      }\n    }\n')
+  for j, n in enumerate(ins):
+    if len(ins) == len(outs):
+      # output j of the previous iteration feeds input j (core.py:342-360)
+      w('    const %s* %s_img = it == 0 ? (const %s*)inputs[%d] : (((it - 1) & 1) ? '
+        'buf_%s_1 : buf_%s_0);\n' % (types[n], n, types[n], j, outs[j], outs[j]))
+    else:
+      w('    const %s* %s_img = (const %s*)inputs[%d];\n' % (types[n], n, types[n], j))
+  for s in stages:
+    n = s['name']
+    if n in outs:
+      w('    %s* %s_img = (it & 1) ? buf_%s_1 : buf_%s_0;\n' % (types[n], n, n, n))
+    else:
+      w('    %s* %s_img = buf_%s_0;\n' % (types[n], n, n))
+
+  def load(name, rel):
+    return '%s_img[%s]' % (name, ' + '.join(
+        '(%c%+d)*stride%d' % (_COORD[d], rel[d], d) for d in range(dim)))
+
+  for s in stages:
+    n = s['name']
+    t = index[n]
+    w('    // produce %s\n' % n)
+    if n in outs:
+      w('    const %s* fpga_%s = (const %s*)device_outputs[%d];\n'
+        % (types[n], n, types[n], outs.index(n)))
+      w('#pragma omp parallel for reduction(+:error_count)\n')
+    else:
+      w('#pragma omp parallel for\n')
+    for d in reversed(range(dim)):
+      w('    for (int32_t {v} = -box_lo[{t}][{d}]; {v} < dims[{d}] - box_hi[{t}][{d}]; '
+        '++{v})\n'.format(v=_COORD[d], t=t, d=d))
+    w('    {\n')
+    for let in s['lets']:
+      w('      const %s %s = %s;\n' % (let['c_type'], let['name'],
+                                      specmod.substitute_loads(let['expr'], load)))
+    cell = ' + '.join('%c*stride%d' % (_COORD[d], d) for d in range(dim))
+    w('      const %s result = %s;\n' % (types[n], specmod.substitute_loads(
+        s['expr'], load)))
+    w('      %s_img[%s] = result;\n' % (n, cell))
+    if n in outs:
+      fmt = ', '.join(['%d'] * dim)
+      coords = ', '.join(_COORD[:dim])
+      w('      if (last) {\n')
+      w('        const %s val_fpga = fpga_%s[%s];\n' % (types[n], n, cell))
+      w('        const %s val_cpu = result;\n' % types[n])
+      if specmod.is_float_type(s['haoda_type']):
+        w('        if (double(val_fpga-val_cpu)*double(val_fpga-val_cpu)/(double('
+          'val_cpu)*double(val_cpu)) > threshold * threshold) {\n')
+        w('          if (error_count < max_report) fprintf(*error_report, '
+          '"%%lf != %%lf @(%s)\\n", double(val_fpga), double(val_cpu), %s);\n'
+          % (fmt, coords))
+      else:
+        w('        if (val_fpga != val_cpu) {\n')
+        w('          if (error_count < max_report) fprintf(*error_report, '
+          '"%%ld != %%ld @(%s)\\n", (long)val_fpga, (long)val_cpu, %s);\n'
+          % (fmt, coords))
+      w('          ++error_count;\n        }\n      }\n')
+    w('    }\n')
+  if len(ins) == len(outs):
+    for j, n in enumerate(ins):
+      w('    for (int d = 0; d < %d; ++d) { box_lo[%d][d] = box_lo[%d][d]; '
+        'box_hi[%d][d] = box_hi[%d][d]; }\n' % (dim, j, index[outs[j]], j,
+                                                index[outs[j]]))
+  w('  }\n')
+  for s in stages:
+    n = s['name']
+    for k in range(2 if n in outs else 1):
+      w('  delete[] buf_%s_%d;\n' % (n, k))
+  w('  return error_count;\n}\n\n')
+
+
 def print_code(spec, kernels, out):
   app = spec['app_name']
   dim = spec['dim']
@@ -40,12 +175,9 @@ def print_code(spec, kernels, out):
   w('// Program hash %s.  Build: g++ -std=c++11 -fopenmp -ffp-contract=off -Iinclude\n'
     % program_hash(spec))
   w('//   %s_host.cpp -Lsoda-compiler_amd/csrc -lsoda_hip\n' % app)
-  for h in ('cassert cfloat cmath cstdbool cstddef cstdint cstdio cstdlib cstring '
-            'algorithm array string unordered_map').split():
-    w('#include <%s>\n' % h)
+  print_prologue(out)
   w('#include "soda_hip.h"\n\n')
   w('typedef soda_hip_buffer_t buffer_t;   // layout of reference header.py:36-48\n')
-  w('static FILE* const* error_report = &stderr;\n\n')
   w('static const char kProgramHash[] = "%s";\n' % program_hash(spec))
   w('static const int kIterate = %d;\n\n' % spec['iterate'])
 
@@ -112,6 +244,7 @@ def print_code(spec, kernels, out):
       app, ''.join('var_%s_buffer, ' % n for n in ins + outs)))
 
   # ---- <app>_test --------------------------------------------------------------
+  print_selfcheck(spec, out)
   w('extern "C" int %s_test(const char* blob, const int dims[4]) {\n' % app)
   w('  const int iterate = getenv("SODA_ITERATE") ? atoi(getenv("SODA_ITERATE")) : '
     'kIterate;\n')
@@ -144,102 +277,15 @@ def print_code(spec, kernels, out):
         '%c*stride%d' % (_COORD[d], d) for d in range(dim)), value))
   w('  const int run_rc = %s_iterate(%sblob, iterate);\n' % (
       app, ''.join('&%s, ' % n for n in ins + outs)))
-  w('  if (run_rc != 0) return run_rc < 0 ? -run_rc : run_rc;\n\n')
-  w('  // CPU re-computation with the plain loop nest, then comparison on the\n')
-  w('  // region the reference compares (host.py:1076-1146)\n')
-  w('  int error_count = 0;\n')
-  nst = len(stages)
-  w('  static const int32_t win[][%d] = {%s};\n' % (2 + 2 * dim, ', '.join(
-      _array([st, pa] + list(lo) + list(hi)) for st, pa, lo, hi in windows)))
-  w('  int32_t box_lo[%d][%d], box_hi[%d][%d];  // per tensor, composed window\n'
-    % (len(index), dim, len(index), dim))
-  w('  memset(box_lo, 0, sizeof box_lo); memset(box_hi, 0, sizeof box_hi);\n')
-  for s in stages:
-    n = s['name']
-    for k in range(2 if n in outs else 1):
-      w('  %s* buf_%s_%d = new %s[cells]();\n' % (types[n], n, k, types[n]))
-  w('  for (int it = 0; it < iterate; ++it) {\n')
-  w('    const bool last = it == iterate - 1;\n')
-  w('    for (int s = %d; s < %d; ++s) {\n' % (len(ins), len(index)))
-  w('      bool first = true;\n')
-  w('      for (size_t k = 0; k < sizeof win / sizeof win[0]; ++k) {\n')
-  w('        if (win[k][0] != s) continue;\n')
-  w('        for (int d = 0; d < %d; ++d) {\n' % dim)
-  w('          const int32_t lo = box_lo[win[k][1]][d] + win[k][2 + d];\n')
-  w('          const int32_t hi = box_hi[win[k][1]][d] + win[k][%d + d];\n' % (2 + dim))
-  w('          box_lo[s][d] = first ? lo : std::min(box_lo[s][d], lo);\n')
-  w('          box_hi[s][d] = first ? hi : std::max(box_hi[s][d], hi);\n')
-  w('        }\n        first = false;\n      }\n    }\n')
-  for j, n in enumerate(ins):
-    if len(ins) == len(outs):
-      w('    const %s* %s_img = it == 0 ? %s_host : (((it - 1) & 1) ? buf_%s_1 : '
-        'buf_%s_0);\n' % (types[n], n, n, outs[j], outs[j]))
-    else:
-      w('    const %s* %s_img = %s_host;\n' % (types[n], n, n))
-  for s in stages:
-    n = s['name']
-    if n in outs:
-      w('    %s* %s_img = (it & 1) ? buf_%s_1 : buf_%s_0;\n' % (types[n], n, n, n))
-    else:
-      w('    %s* %s_img = buf_%s_0;\n' % (types[n], n, n))
-
-  def load(name, rel):
-    return '%s_img[%s]' % (name, ' + '.join(
-        '(%c%+d)*stride%d' % (_COORD[d], rel[d], d) for d in range(dim)))
-
-  for s in stages:
-    n = s['name']
-    t = index[n]
-    w('    // produce %s\n' % n)
-    if n in outs:
-      w('#pragma omp parallel for reduction(+:error_count)\n')
-    else:
-      w('#pragma omp parallel for\n')
-    for d in reversed(range(dim)):
-      w('    for (int32_t {v} = -box_lo[{t}][{d}]; {v} < dims[{d}] - box_hi[{t}][{d}]; '
-        '++{v})\n'.format(v=_COORD[d], t=t, d=d))
-    w('    {\n')
-    for let in s['lets']:
-      w('      const %s %s = %s;\n' % (let['c_type'], let['name'],
-                                      specmod.substitute_loads(let['expr'], load)))
-    cell = ' + '.join('%c*stride%d' % (_COORD[d], d) for d in range(dim))
-    w('      const %s result = %s;\n' % (types[n], specmod.substitute_loads(
-        s['expr'], load)))
-    w('      %s_img[%s] = result;\n' % (n, cell))
-    if n in outs:
-      fmt = ', '.join(['%d'] * dim)
-      coords = ', '.join(_COORD[:dim])
-      w('      if (last) {\n')
-      w('        const %s val_fpga = %s_host[%s];\n' % (types[n], n, cell))
-      w('        const %s val_cpu = result;\n' % types[n])
-      if specmod.is_float_type(s['haoda_type']):
-        w('        double threshold = 0.00001;\n')
-        w('        if (nullptr != getenv("THRESHOLD")) threshold = '
-          'atof(getenv("THRESHOLD"));\n')
-        w('        threshold *= threshold;\n')
-        w('        if (double(val_fpga-val_cpu)*double(val_fpga-val_cpu)/(double('
-          'val_cpu)*double(val_cpu)) > threshold) {\n')
-        w('          if (error_count < 32) fprintf(*error_report, "%%lf != %%lf @(%s)'
-          '\\n", double(val_fpga), double(val_cpu), %s);\n' % (fmt, coords))
-      else:
-        w('        if (val_fpga != val_cpu) {\n')
-        w('          if (error_count < 32) fprintf(*error_report, "%%ld != %%ld @(%s)'
-          '\\n", (long)val_fpga, (long)val_cpu, %s);\n' % (fmt, coords))
-      w('          ++error_count;\n        }\n      }\n')
-    w('    }\n')
-  # feed: box of input j for the next iteration = box of output j
-  if len(ins) == len(outs):
-    for j, n in enumerate(ins):
-      w('    for (int d = 0; d < %d; ++d) { box_lo[%d][d] = box_lo[%d][d]; '
-        'box_hi[%d][d] = box_hi[%d][d]; }\n' % (dim, j, index[outs[j]], j,
-                                                index[outs[j]]))
-  w('  }\n')
+  w('  if (run_rc != 0) return run_rc < 0 ? -run_rc : run_rc;\n')
+  w('  double threshold = 0.00001;\n')
+  w('  if (nullptr != getenv("THRESHOLD")) threshold = atof(getenv("THRESHOLD"));\n')
+  w('  const void* in_ptrs[] = {%s};\n' % ', '.join('%s_host' % n for n in ins))
+  w('  const void* out_ptrs[] = {%s};\n' % ', '.join('%s_host' % n for n in outs))
+  w('  const int error_count = (int)%s_selfcheck(in_ptrs, out_ptrs, dims, iterate, '
+    'threshold, 32);\n' % app)
   w('  fprintf(*error_report, error_count == 0 ? "INFO: PASS!\\n" : '
     '"INFO: FAIL!\\n");\n')
-  for s in stages:
-    n = s['name']
-    for k in range(2 if n in outs else 1):
-      w('  delete[] buf_%s_%d;\n' % (n, k))
   for n in ins + outs:
     w('  delete[] %s_host;\n' % n)
   w('  return error_count;\n}\n\n')

@@ -240,8 +240,8 @@ class _Parser:
     if self.peek().text in ('+', '-'):
       sign = -1 if self.next().text == '-' else 1
     tok = self.peek()
-    if tok.kind != 'num' or re.search(r'[.]|^\d+[Ee]|^\d.*[Ff]$', tok.text) \
-        and not tok.text.lower().startswith('0x'):
+    if tok.kind != 'num' or not re.match(
+        r'(?:0[Xx][0-9a-fA-F]+|0[Bb][01]+|\d+)[UuLl]*\Z', tok.text):
       self.fail('expected an integer, found %r' % (tok.text or 'end of file'))
     text = self.next().text.rstrip('UuLl')
     low = text.lower()

@@ -206,3 +206,41 @@ def test_compilation_sweep_like_the_reference_script(app, tmp_path):
     subprocess.check_call(['/opt/rocm/bin/hipcc'] + flags +
                           kernel.flags_from_text(r.stdout) +
                           ['-fsyntax-only', str(src)])
+
+
+@pytest.mark.parametrize('app,shape,iterate', [
+    ('jacobi2d', (40, 50), 3), ('blur', (33, 47), 1), ('denoise2d', (30, 40), 1),
+    ('heat3d', (12, 14, 16), 2), ('sobel2d', (30, 44), 2)])
+def test_selfcheck_of_app_test_counts_mismatches(app, shape, iterate):
+  """The CPU half of `<app>_test` (reference host.py:1073-1146): zero mismatches
+  on a correct result, exactly the corrupted cells otherwise; corruption outside
+  the compared region is ignored, as in the reference."""
+  import numpy as np
+  from soda_hip.runtime import selfcheck
+  from oracle import soda_oracle
+  spec = spec_of(app)
+  orc = soda_oracle.Oracle(spec)
+  rng = np.random.default_rng(1)
+  ins = []
+  for t in spec['inputs']:
+    dt = np.dtype(specmod.NUMPY_NAME[t['c_type']])
+    ins.append(rng.random(shape, dtype=np.float32).astype(dt) if dt.kind == 'f'
+               else rng.integers(0, 256, size=shape).astype(dt))
+  want = orc.run(ins, iterate=iterate)
+  outs = [want[o] for o in spec['outputs']]
+  assert selfcheck.count_mismatches(spec, ins, outs, iterate) == 0
+  sl = orc.valid_slices(tuple(reversed(shape)), iterate)
+  bad = [o.copy() for o in outs]
+  inside = tuple(s.start + 1 for s in sl)
+  bad[0][inside] += 1
+  bad[0][tuple(0 for _ in shape)] += 1        # outside the compared region
+  assert selfcheck.count_mismatches(spec, ins, bad, iterate, max_report=0) == 1
+
+
+def test_parser_integer_forms():
+  from soda_hip.frontend.parser import _Parser
+  for text, value in (('0x1F', 31), ('-0b101', -5), ('017', 15), ('42u', 42),
+                      ('+7', 7)):
+    assert _Parser(text).c_int() == value
+  with pytest.raises(Exception):
+    _Parser('1.5').c_int()
