@@ -233,7 +233,7 @@ def test_selfcheck_of_app_test_counts_mismatches(app, shape, iterate):
   bad = [o.copy() for o in outs]
   inside = tuple(s.start + 1 for s in sl)
   bad[0][inside] += 1
-  bad[0][tuple(0 for _ in shape)] += 1        # outside the compared region
+  bad[0][tuple(n - 1 for n in shape)] += 1    # outside the compared region
   assert selfcheck.count_mismatches(spec, ins, bad, iterate, max_report=0) == 1
 
 
