@@ -113,6 +113,11 @@ void grow_boxes(soda_hip_plan* plan, int iterations) {
         }
         acc.set = true;
       }
+      // the cell itself must lie inside the array: boxes contain the origin
+      for (int d = 0; d < p.dim; ++d) {
+        acc.lo[d] = std::min<int32_t>(acc.lo[d], 0);
+        acc.hi[d] = std::max<int32_t>(acc.hi[d], 0);
+      }
       cur[t] = acc;
     }
     if (p.n_inputs == p.n_outputs)
@@ -188,6 +193,14 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
   out->kernel = k;
   out->args = args;
   *empty = false;
+  // never launch a box that sticks out of the array
+  for (int d = 0; d < dim; ++d)
+    if (args.box_hi[d] > args.box_lo[d] &&
+        (args.box_lo[d] < 0 || args.box_hi[d] > args.dims[d]))
+      return fail(SODA_HIP_ERR_OUT_OF_BOUNDS,
+                  "kernel %s: box [%lld, %lld) outside dimension %d of extent %lld",
+                  desc.name, (long long)args.box_lo[d], (long long)args.box_hi[d], d,
+                  (long long)args.dims[d]);
   for (int d = 0; d < 3; ++d) out->grid[d] = 1;
   if (dim > 3) return fail(SODA_HIP_ERR_INTERNAL, "4-D launches are not implemented");
   for (int d = 0; d < dim; ++d) {
@@ -229,14 +242,18 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
 }
 
 int check_box_inside(const soda_hip_plan* plan, const soda_hip_args& a,
-                     const int32_t* reach_lo, const int32_t* reach_hi) {
-  // every cell a launch may read must be inside the array: the kernels rely on it
+                     const int32_t* reach_lo, const int32_t* reach_hi,
+                     bool signed_window = false) {
+  // every cell a launch may read must be inside the array: the kernels rely on
+  // it.  reach_* are margins (>= 0) or, with signed_window, window offsets
+  // (lo <= hi, either sign).
   for (int d = 0; d < plan->prog.dim; ++d) {
     if (a.box_hi[d] <= a.box_lo[d]) continue;
-    if (a.box_lo[d] - reach_lo[d] < 0 || a.box_hi[d] + reach_hi[d] > a.dims[d])
+    const int64_t first = signed_window ? a.box_lo[d] + reach_lo[d] : a.box_lo[d] - reach_lo[d];
+    if (first < 0 || a.box_hi[d] + reach_hi[d] > a.dims[d])
       return fail(SODA_HIP_ERR_OUT_OF_BOUNDS,
                   "launch would read [%lld, %lld) of dimension %d, extent %lld",
-                  (long long)(a.box_lo[d] - reach_lo[d]),
+                  (long long)first,
                   (long long)(a.box_hi[d] + reach_hi[d]), d, (long long)a.dims[d]);
   }
   return 0;
@@ -370,6 +387,12 @@ int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
       for (int d = 0; d < SODA_HIP_MAX_DIMS; ++d) {
         a.box_lo[d] = d < p.dim ? vlo[d] - b.lo[d] : 0;
         a.box_hi[d] = d < p.dim ? dims[d] - vhi[d] - b.hi[d] : 1;
+      }
+      // everything the stage reads must be inside the array
+      for (int w = 0; w < p.n_windows; ++w) {
+        if (p.window[w].stage != p.n_inputs + s) continue;
+        int rc = check_box_inside(plan, a, p.window[w].lo, p.window[w].hi, true);
+        if (rc) return rc;
       }
       Launch l;
       bool empty;

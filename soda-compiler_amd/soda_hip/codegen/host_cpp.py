@@ -86,7 +86,12 @@ def print_selfcheck(spec, out):
   w('          const int32_t hi = box_hi[win[k][1]][d] + win[k][%d + d];\n' % (2 + dim))
   w('          box_lo[s][d] = first ? lo : std::min(box_lo[s][d], lo);\n')
   w('          box_hi[s][d] = first ? hi : std::max(box_hi[s][d], hi);\n')
-  w('        }\n        first = false;\n      }\n    }\n')
+  w('        }\n        first = false;\n      }\n')
+  w('      for (int d = 0; d < %d; ++d) {  // the cell itself is inside the array\n'
+    % dim)
+  w('        box_lo[s][d] = std::min(box_lo[s][d], 0);\n')
+  w('        box_hi[s][d] = std::max(box_hi[s][d], 0);\n')
+  w('      }\n    }\n')
   for j, n in enumerate(ins):
     if len(ins) == len(outs):
       # output j of the previous iteration feeds input j (core.py:342-360)

@@ -31,15 +31,17 @@ HIPCC_FLAGS = ['-x', 'hip', '--offload-arch=gfx950', '--cuda-device-only',
 def extra_flags(spec):
   """Per-program compiler flags beyond HIPCC_FLAGS.
 
-  ROCm 7.2's DPP-combine pass miscompiles the fused kernels of programs with
-  8/16-bit elements (a wave-shift DPP mov folded into a 16-bit VALU op gives
-  wrong values once intermediates exceed 16 bits before truncation: sobel2d at
-  depth >= 2; found by the parity tests, -O0 and -amdgpu-dpp-combine=false are
-  both correct).  Those programs are compiled with the pass off; 32/64-bit
-  programs keep it (their fused DPP adds are verified bit-exact)."""
-  sizes = [specmod.ELEM_SIZE[t] for t in specmod.tensor_c_types(spec).values()]
-  if min(sizes) < 4:
-    return ['-mllvm', '-amdgpu-dpp-combine=false']
+  ROCm 7.2's DPP-combine pass (GCNDPPCombine) miscompiles INTEGER subtraction
+  whose operand is a wave-shift DPP move: folding `v_mov_b32_dpp` into
+  `v_sub[rev]_u32` / `v_sub[rev]_u16` gives wrong values in every lane.  Found by
+  the parity tests (sobel2d at depth >= 2; `o = l - a(2,0) + a(-2,0)` on int32);
+  -O0 and -amdgpu-dpp-combine=false are both correct, float subtraction and
+  integer addition are not affected.  Programs with any integer tensor are
+  therefore compiled with the pass off; float programs keep it (their fused DPP
+  adds/subs are verified bit-exact, and the fusion is worth ~10 % there)."""
+  for ctype in specmod.tensor_c_types(spec).values():
+    if ctype not in ('float', 'double', '_Float16'):
+      return ['-mllvm', '-amdgpu-dpp-combine=false']
   return []
 
 

@@ -224,7 +224,8 @@ def iteration_boxes(spec, iterations):
         chi = [a + b for a, b in zip(phi, whi)]
         lo = clo if lo is None else [min(a, b) for a, b in zip(lo, clo)]
         hi = chi if hi is None else [max(a, b) for a, b in zip(hi, chi)]
-      boxes[stage['name']] = (lo, hi)
+      # the cell itself must be inside the array: boxes contain the origin
+      boxes[stage['name']] = ([min(0, v) for v in lo], [max(0, v) for v in hi])
     result.append({s['name']: boxes[s['name']] for s in spec['stages']})
     if len(in_names) == len(spec['outputs']):
       feed = {i: boxes[o] for i, o in zip(in_names, spec['outputs'])}

@@ -248,7 +248,11 @@ class Stencil:
         acc = None
         for parent, win in self.stage_window(self.stages[name]).items():
           acc = boxes[parent].shifted(win.lo, win.hi).hull(acc)
-        boxes[name] = acc
+        # a cell also has to lie inside the array itself: the box always
+        # contains the origin.  (The reference lets the loop start at a negative
+        # index for a window that lies entirely on one side of the store point,
+        # host.py:1082-1091 with core.py:832-835 -- undefined behaviour there.)
+        boxes[name] = acc.hull(Box.origin(self.dim))
       result.append({n: boxes[n] for n in self.order})
       if len(self.input_names) == len(self.output_names):
         feed = {i: boxes[o]

@@ -143,10 +143,15 @@ def test_fill_prologue_start_steps():
     assert 'if (n + 0 >= %d) {' % (3 + 2 * t) in text
 
 
-def test_narrow_types_disable_dpp_combine():
+def test_integer_programs_disable_dpp_combine():
   assert kernel.extra_flags(spec_of('blur')) == ['-mllvm',
                                                  '-amdgpu-dpp-combine=false']
   assert kernel.extra_flags(spec_of('jacobi2d')) == []
+  assert kernel.extra_flags(spec_of('denoise3d')) == []
+  int32 = specmod.spec_from_stencil(frontend.loads(
+      'kernel: k\nburst width: 512\nunroll factor: 1\niterate: 2\n'
+      'input int32: a(8, *)\noutput int32: o(0, 0) = a(0, 0) - a(2, 0) + a(-2, 0)\n'))
+  assert kernel.extra_flags(int32) == ['-mllvm', '-amdgpu-dpp-combine=false']
   text, _ = kernel.generate(spec_of('sobel2d'))
   assert kernel.flags_from_text(text) == ['-mllvm', '-amdgpu-dpp-combine=false']
 
