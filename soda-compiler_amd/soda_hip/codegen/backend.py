@@ -114,7 +114,7 @@ def print_code(stencil, args):
   if files['host_cpp']:
     _logger.info('generate C++ host as %s', files['host_cpp'])
     f, close = _open(files['host_cpp'])
-    host_cpp.print_code(spec, table, f)
+    host_cpp.print_code(spec, table, f, lowered=specmod.inline_pointwise(spec))
     if close:
       f.close()
   if files['blob']:

@@ -163,7 +163,10 @@ def print_selfcheck(spec, out):
   w('  return error_count;\n}\n\n')
 
 
-def print_code(spec, kernels, out):
+def print_code(spec, kernels, out, lowered=None):
+  """`spec`: the source program (golden loops, entry points); `lowered`: the
+  program the kernels were generated from (descriptor literals)."""
+  lowered = spec if lowered is None else lowered
   app = spec['app_name']
   dim = spec['dim']
   types = specmod.tensor_c_types(spec)
@@ -186,20 +189,26 @@ def print_code(spec, kernels, out):
   w('static const char kProgramHash[] = "%s";\n' % program_hash(spec))
   w('static const int kIterate = %d;\n\n' % spec['iterate'])
 
-  # ---- descriptors ------------------------------------------------------------
+  # ---- descriptors (of the LOWERED program the kernels implement) ------------
+  low_index = tensor_index(lowered)
+  low_types = specmod.tensor_c_types(lowered)
+  low_windows = []
+  for stage, wins in specmod.stage_windows(lowered).items():
+    for parent, (lo, hi) in wins.items():
+      low_windows.append((low_index[stage], low_index[parent], lo, hi))
   w('static void fill_program(soda_hip_program* p) {\n')
   w('  memset(p, 0, sizeof *p);\n')
   w('  p->dim = %d; p->n_inputs = %d; p->n_stages = %d; p->n_outputs = %d;\n'
-    % (dim, len(ins), len(stages), len(outs)))
-  sizes = [0] * len(index)
-  for n, i in index.items():
-    sizes[i] = specmod.ELEM_SIZE[types[n]]
+    % (dim, len(ins), len(lowered['stages']), len(outs)))
+  sizes = [0] * len(low_index)
+  for n, i in low_index.items():
+    sizes[i] = specmod.ELEM_SIZE[low_types[n]]
   w('  static const int32_t elem[] = %s;\n' % _array(sizes))
   w('  for (int i = 0; i < %d; ++i) p->elem_size[i] = elem[i];\n' % len(sizes))
   for j, o in enumerate(outs):
-    w('  p->output_tensor[%d] = %d;\n' % (j, index[o]))
-  w('  p->n_windows = %d;\n' % len(windows))
-  for k, (st, pa, lo, hi) in enumerate(windows):
+    w('  p->output_tensor[%d] = %d;\n' % (j, low_index[o]))
+  w('  p->n_windows = %d;\n' % len(low_windows))
+  for k, (st, pa, lo, hi) in enumerate(low_windows):
     w('  { soda_hip_window* v = &p->window[%d]; v->stage = %d; v->parent = %d;' % (
         k, st, pa))
     for d in range(dim):

@@ -76,13 +76,17 @@ def fused_depths(spec, max_depth):
 
 
 def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
-             fused=True, depths=None, **fused_options):
+             fused=True, depths=None, inline=True, **fused_options):
   """Returns (kernel text, kernel table).  `depths` overrides the default set
   of fused depths (depth 1 is always included: the scheduler needs it)."""
   max_depth = DEFAULT_MAX_DEPTH if max_depth is None else max_depth
-  parts = [kernel_common.prelude(spec, __version__)]
-  if extra_flags(spec):
-    parts.append('%s %s\n' % (FLAGS_MARK, ' '.join(extra_flags(spec))))
+  # kernels are generated from the LOWERED program (pointwise-only locals folded
+  # into their readers); the blob is still identified by the source program
+  source = spec
+  spec = specmod.inline_pointwise(spec) if inline else spec
+  parts = [kernel_common.prelude(source, __version__)]
+  if extra_flags(source):
+    parts.append('%s %s\n' % (FLAGS_MARK, ' '.join(extra_flags(source))))
   wrappers = kernel_common.math_wrappers(kernel_common.used_functions(spec))
   if wrappers:
     parts.append('// math calls resolve as in the reference CPU path: C double '
@@ -111,16 +115,28 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
     if depths is not None:
       wanted3 = sorted(set([1] + list(depths))) if len(wanted3) > 1 else [1]
     for depth in wanted3:
-      try:
-        ftext, entry = kernel_stream3d.emit(spec, depth, **fused_options)
-      except kernel_stream2d.NotFusable as e:
-        notes.append('depth %d not fused: %s' % (depth, e))
-        continue
-      parts.append(ftext)
-      table.append(entry)
+      # rows per lane: as many as the register file allows (taller tiles waste
+      # less on the y halo)
+      options = dict(fused_options)
+      row_choices = [options.pop("rows")] if "rows" in options else [16, 12]
+      error = None
+      for rows in row_choices:
+        try:
+          ftext, entry = kernel_stream3d.emit(spec, depth, rows=rows, **options)
+        except kernel_stream2d.NotFusable as e:
+          error = e
+          continue
+        parts.append(ftext)
+        table.append(entry)
+        error = None
+        break
+      if error is not None:
+        notes.append('depth %d not fused: %s' % (depth, error))
   if notes:
     parts.append(''.join('// %s\n' % n for n in notes))
-  parts.append(kernel_common.meta_symbol(spec, table))
+  parts.append(kernel_common.meta_symbol(
+      spec, table, extra=dict(program_hash=kernel_common.program_hash(source),
+                              source_stages=[s['name'] for s in source['stages']])))
   return '\n'.join(parts), table
 
 

@@ -232,6 +232,53 @@ def iteration_boxes(spec, iterations):
   return result
 
 
+def inline_pointwise(spec):
+  """Lowers a spec by folding away every local stage that all its readers read
+  ONLY at offset 0 (diff_u, r0, r1 ... of the denoise programs): each
+  `{L:0,0}` in a reader becomes `static_cast<T_L >(<L's expression>)`, L
+  disappears from the stage list.  The arithmetic is unchanged -- the same
+  operations in the same order, the cast reproducing the rounding of L's store
+  -- but L no longer costs an array pass (per-stage kernels) or a register
+  window (fused kernels).  Stages with `let`s are left alone.  Returns a new
+  spec; inputs, outputs and composed windows are the same as the original's."""
+  import copy
+  spec = copy.deepcopy(spec)
+  dim = spec['dim']
+  zero = [0] * dim
+  outs = set(spec['outputs'])
+  while True:
+    victim = None
+    for stage in spec['stages']:
+      name = stage['name']
+      if name in outs or stage['lets']:
+        continue
+      readers = [s for s in spec['stages']
+                 if any(t == name for t, _ in s['loads'])]
+      if not readers:
+        continue
+      if all(rel == zero for s in readers for t, rel in s['loads'] if t == name):
+        victim = stage
+        break
+    if victim is None:
+      return spec
+    name = victim['name']
+    inlined = 'static_cast<%s >(%s)' % (victim['c_type'], victim['expr'])
+    hole = load_placeholder(name, zero)
+    for s in spec['stages']:
+      if not any(t == name for t, _ in s['loads']):
+        continue
+      s['expr'] = s['expr'].replace(hole, inlined)
+      for let in s['lets']:
+        let['expr'] = let['expr'].replace(hole, inlined)
+      merged = []
+      for t, rel in s['loads']:
+        for item in (victim['loads'] if t == name else [[t, rel]]):
+          if item not in merged:
+            merged.append([item[0], list(item[1])])
+      s['loads'] = merged
+    spec['stages'] = [s for s in spec['stages'] if s['name'] != name]
+
+
 def iteration_margins(spec, iterations):
   """[(lo, hi)] per iteration for the program outputs (hull over outputs), as
   non-negative margins: after k+1 iterations outputs live on [lo_d, N_d-hi_d)."""

@@ -198,7 +198,10 @@ class Program:
                 program_hash(spec)[:12]))
     self.spec = meta['spec'] if spec is None else spec
     self.kernels = meta['kernels']
-    self._desc = program_desc(self.spec)
+    # the plan runs the LOWERED program the kernels were generated from
+    # (pointwise-only locals folded away); inputs and outputs are the source's
+    self.lowered = meta['spec']
+    self._desc = program_desc(self.lowered)
     self._kdesc = kernel_descs(self.kernels)
     h = ctypes.c_void_p()
     capi.check(capi.lib().soda_hip_plan_create(

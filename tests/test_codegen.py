@@ -99,8 +99,10 @@ def test_every_sample_compiles_for_gfx950(app, tmp_path):
   kernel.compile_to_code_object(text, str(out))
   assert out.stat().st_size > 1000
   assert open(out, 'rb').read(4) == b'\x7fELF'
+  # one per-stage kernel per stage of the LOWERED program (locals that are only
+  # read at offset 0 are folded into their readers)
   stages = [k for k in table if k['kind'] == 'stage']
-  assert len(stages) == len(spec['stages'])
+  assert len(stages) == len(specmod.inline_pointwise(spec)['stages'])
 
 
 def test_pipeline_lags_match_the_reference_reuse_model():
@@ -131,6 +133,28 @@ def test_unfusable_programs_fall_back_to_stage_kernels():
   # multi-input 2-D programs fuse at depth 1 with padded window lengths
   _, table = kernel.generate(spec_of('denoise2d'))
   assert [k['depth'] for k in table if k['kind'] == 'fused'] == [1]
+
+
+def test_pointwise_locals_are_folded_into_their_readers():
+  """denoise: diff_*, r0, r1 are read only at offset 0 -> two stages remain; the
+  cast reproduces the rounding of the removed store; windows are unchanged."""
+  for app, kept in (('denoise2d', ['g', 'output']), ('denoise3d', ['g', 'output']),
+                    ('sobel2d', ['mag']), ('blur', ['blur_x', 'blur_y']),
+                    ('jacobi2d', ['t0'])):
+    spec = spec_of(app)
+    low = specmod.inline_pointwise(spec)
+    assert [s['name'] for s in low['stages']] == kept
+    assert specmod.iteration_margins(low, 1) == specmod.iteration_margins(spec, 1)
+    assert low['inputs'] == spec['inputs'] and low['outputs'] == spec['outputs']
+  g = specmod.inline_pointwise(spec_of('denoise2d'))['stages'][0]
+  assert 'static_cast<float >(({u:0,0} - {u:0,-1}))' in g['expr']
+  assert sorted(map(tuple, (r for _, r in g['loads']))) == \
+      [(-1, 0), (0, -1), (0, 0), (0, 1), (1, 0)]
+  # the blob is still identified by the SOURCE program
+  text, _ = kernel.generate(spec_of('denoise2d'))
+  meta = kernel_common.read_meta_from_source(text)
+  assert meta['program_hash'] == kernel_common.program_hash(spec_of('denoise2d'))
+  assert [s['name'] for s in meta['spec']['stages']] == ['g', 'output']
 
 
 def test_fill_prologue_start_steps():
