@@ -244,6 +244,15 @@ def run_single(args):
 def main():
   args = parse_args()
   world = int(os.environ.get('WORLD_SIZE', '1'))
+  if args.gpus > 1 and 'RANK' not in os.environ:
+    # started by hand without a launcher: start one rank per GPU as CHILD
+    # processes (nothing here has touched the GPU yet) and pass their status on
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', os.environ.get('MASTER_PORT', '29533'),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
   if args.gpus > 1 or world > 1 or args.force_dist:
     from soda_hip.runtime import dist
     result = dist.bench_main(args, open_program, make_input, cpu_baseline,

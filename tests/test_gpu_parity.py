@@ -403,3 +403,39 @@ def test_denormals_signed_zeros_and_infinities():
                           want[sl][finite].view(np.uint32))
     assert (got[sl][finite] != 0).any()
   prog.set_max_depth(0)
+
+
+def test_grid_beyond_2_to_31_elements():
+  """64-bit indexing: 50000 x 43000 floats = 2.15e9 cells (8.6 GB per array),
+  13 iterations (one depth-12 + one depth-1 launch).  Bands of rows at the top,
+  just below and above the 2^31-element boundary and at the bottom are compared
+  with the oracle run on sub-grids containing their dependency cones."""
+  w, h, it = 50000, 43000, 13
+  assert w * h > 2 ** 31
+  prog = program('jacobi2d')
+  cols = (np.arange(w, dtype=np.int64) * 7 % 1013).astype(np.float32) / np.float32(1013)
+  rows = (np.arange(h, dtype=np.int64) * 13 % 997).astype(np.float32) / np.float32(997)
+  a = np.empty((h, w), dtype=np.float32)
+  np.add(rows[:, None], cols[None, :], out=a)
+  din = host.DeviceArray(a.nbytes)
+  dout = host.DeviceArray(a.nbytes)
+  try:
+    din.upload(a)
+    prog.set_max_depth(0)
+    prog.sweep([din.ptr], [dout.ptr], [w, h], it)
+    host.capi.check(host.capi.lib().soda_hip_stream_synchronize(None))
+    boundary_row = 2 ** 31 // w          # first row whose cells pass 2^31
+    for first in (it, boundary_row - 8, boundary_row + 1, h - it - 16):
+      band = np.empty((16, w), dtype=np.float32)
+      host.capi.check(host.capi.lib().soda_hip_memcpy_d2h(
+          band.ctypes.data, dout.ptr + first * w * 4, band.nbytes, None))
+      host.capi.check(host.capi.lib().soda_hip_stream_synchronize(None))
+      sub = np.ascontiguousarray(a[first - it:first + 16 + it])
+      want = oracle('jacobi2d').run([sub], iterate=it)['t0'][it:it + 16]
+      assert np.array_equal(band[:, it:w - it], want[:, it:w - it]), first
+      assert band[:, it:w - it].std() > 0
+  finally:
+    din.free()
+    dout.free()
+    prog.close()
+    _PROGRAMS.pop('jacobi2d', None)
