@@ -14,6 +14,7 @@ The unit holds
     libsoda_hip.so reads back from the loaded blob.
 """
 import os
+import re
 import subprocess
 import tempfile
 
@@ -28,21 +29,40 @@ HIPCC_FLAGS = ['-x', 'hip', '--offload-arch=gfx950', '--cuda-device-only',
                '-fno-slp-vectorize', '-fwrapv', '-std=c++17']
 
 
+_DOUBLE_LITERAL = re.compile(
+    r'(?<![\w.])(?:\d+\.\d*|\.\d+|\d+(?=[eE]))(?:[eE][+-]?\d+)?(?![\w.])')
+
+
+def dpp_combine_is_safe(spec):
+  """True for programs whose arithmetic is float32 only: every tensor `float`,
+  no double literal, no math call (those are the C double functions), no cast."""
+  if any(t != 'float' for t in specmod.tensor_c_types(spec).values()):
+    return False
+  for stage in spec['stages']:
+    for text in [stage['expr']] + [l['expr'] for l in stage['lets']]:
+      plain = specmod.LOAD_RE.sub('x', text)
+      if _DOUBLE_LITERAL.search(plain) or kernel_common.used_functions(
+          dict(stages=[dict(expr=text, lets=[])])) or 'static_cast<' in plain:
+        return False
+  return True
+
+
 def extra_flags(spec):
   """Per-program compiler flags beyond HIPCC_FLAGS.
 
-  ROCm 7.2's DPP-combine pass (GCNDPPCombine) miscompiles INTEGER subtraction
-  whose operand is a wave-shift DPP move: folding `v_mov_b32_dpp` into
-  `v_sub[rev]_u32` / `v_sub[rev]_u16` gives wrong values in every lane.  Found by
-  the parity tests (sobel2d at depth >= 2; `o = l - a(2,0) + a(-2,0)` on int32);
-  -O0 and -amdgpu-dpp-combine=false are both correct, float subtraction and
-  integer addition are not affected.  Programs with any integer tensor are
-  therefore compiled with the pass off; float programs keep it (their fused DPP
-  adds/subs are verified bit-exact, and the fusion is worth ~10 % there)."""
-  for ctype in specmod.tensor_c_types(spec).values():
-    if ctype not in ('float', 'double', '_Float16'):
-      return ['-mllvm', '-amdgpu-dpp-combine=false']
-  return []
+  ROCm 7.2's DPP-combine pass (GCNDPPCombine) is only trusted on pure-float32
+  programs.  Found by the parity tests:
+    * INTEGER subtraction whose operand is a wave-shift DPP move is miscompiled
+      (`v_mov_b32_dpp` folded into `v_sub[rev]_u32/_u16`: every lane wrong;
+      sobel2d at depth >= 2, `o = l - a(2,0) + a(-2,0)` on int32);
+    * a DPP move folded into `v_cvt_f64_f32` (a float operand meeting a double
+      literal) yields an instruction the verifier rejects: the compile fails.
+  -O0 and -amdgpu-dpp-combine=false are correct in both cases.  Float32
+  add/sub/mul with a DPP operand is verified bit-exact and the fusion is worth
+  ~10 % on the jacobi kernels, so float32-only programs keep the pass."""
+  if dpp_combine_is_safe(spec):
+    return []
+  return ['-mllvm', '-amdgpu-dpp-combine=false']
 
 
 FLAGS_MARK = '// SODA-HIP-FLAGS:'

@@ -167,17 +167,25 @@ def test_fill_prologue_start_steps():
     assert 'if (n + 0 >= %d) {' % (3 + 2 * t) in text
 
 
-def test_integer_programs_disable_dpp_combine():
-  assert kernel.extra_flags(spec_of('blur')) == ['-mllvm',
-                                                 '-amdgpu-dpp-combine=false']
-  assert kernel.extra_flags(spec_of('jacobi2d')) == []
-  assert kernel.extra_flags(spec_of('denoise3d')) == []
-  int32 = specmod.spec_from_stencil(frontend.loads(
-      'kernel: k\nburst width: 512\nunroll factor: 1\niterate: 2\n'
-      'input int32: a(8, *)\noutput int32: o(0, 0) = a(0, 0) - a(2, 0) + a(-2, 0)\n'))
-  assert kernel.extra_flags(int32) == ['-mllvm', '-amdgpu-dpp-combine=false']
+def test_dpp_combine_only_for_pure_float32_programs():
+  off = ['-mllvm', '-amdgpu-dpp-combine=false']
+  for app in ('jacobi2d', 'jacobi3d', 'seidel2d', 'heat3d'):
+    assert kernel.extra_flags(spec_of(app)) == []
+  for app in ('blur', 'sobel2d', 'denoise2d', 'denoise3d'):   # ints / double math
+    assert kernel.extra_flags(spec_of(app)) == off
+  head = ('kernel: k\nburst width: 512\nunroll factor: 1\niterate: 2\n'
+          'input %s: a(8, *)\noutput %s: o(0, 0) = ')
+
+  def flags(ty, expr):
+    return kernel.extra_flags(specmod.spec_from_stencil(
+        frontend.loads(head % (ty, ty) + expr + '\n')))
+  assert flags('int32', 'a(0, 0) - a(2, 0) + a(-2, 0)') == off
+  assert flags('float', 'a(0, 0) * 0.3 + a(1, 0) * 2.f') == off        # double literal
+  assert flags('float', 'a(0, 0) * 1e3 + a(1, 0)') == off
+  assert flags('float', 'a(0, 0) * .5f + a(1, 0) * 2.f + a(0, 1) * 3') == []
+  assert flags('double', 'a(0, 0) * 0.5 + a(1, 0)') == off
   text, _ = kernel.generate(spec_of('sobel2d'))
-  assert kernel.flags_from_text(text) == ['-mllvm', '-amdgpu-dpp-combine=false']
+  assert kernel.flags_from_text(text) == off
 
 
 def test_program_desc_for_the_c_abi():

@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 def random_program(rng, seed):
   dim = 3 if rng.random() < 0.25 else 2
   floaty = rng.random() < 0.6
-  dtype = 'float' if floaty else rng.choice(['uint16', 'int32'])
+  dtype = rng.choice(['float', 'float', 'float', 'double']) if floaty else \
+      rng.choice(['uint16', 'int32', 'int32', 'uint8', 'int64', 'int16'])
   n_inputs = 1 if rng.random() < 0.75 else 2
   n_locals = int(rng.integers(0, 4))
   iterate = int(rng.integers(1, 6)) if n_inputs == 1 else 1
@@ -47,7 +48,7 @@ def random_program(rng, seed):
 
   def literal():
     if floaty:
-      return rng.choice(['0.25f', '0.5f', '1.5f', '0.125f', '3.0f', '0.2f'])
+      return rng.choice(['0.25f', '0.5f', '1.5f', '0.125f', '3.0f', '0.2f', '0.3'])
     return str(int(rng.integers(1, 5)))
 
   def expression(available, must_use):
@@ -106,7 +107,7 @@ def test_random_program(seed):
   for t in spec['inputs']:
     dt = np.dtype(specmod.NUMPY_NAME[t['c_type']])
     if dt.kind == 'f':
-      inputs.append(rng.random(shape, dtype=np.float32) + np.float32(0.5))
+      inputs.append((rng.random(shape, dtype=np.float32) + np.float32(0.5)).astype(dt))
     else:
       inputs.append(rng.integers(0, 200, size=shape).astype(dt))
   orc = soda_oracle.Oracle(spec)
