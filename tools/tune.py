@@ -31,7 +31,7 @@ for variant in sys.argv[4:]:
   except Exception as e:
     print(variant, 'FAILED', str(e)[:300]); continue
   tc = time.time() - t0
-  t = prog.sweep_timed([din.ptr], [dout.ptr], dims, iterate, warmup=6, repeats=6)
+  t = prog.sweep_timed([din.ptr], [dout.ptr], dims, iterate, warmup=int(os.environ.get("TUNE_WARMUP", "6")), repeats=int(os.environ.get("TUNE_REPEATS", "6")))
   valid = specmod.valid_cells(spec, dims, iterate)
   print('%-28s compile %.1fs  %8.1f us/sweep  %d launches  dominant %s %.1f us  -> %.0f Gcell/s valid (%.0f nominal)' % (
       variant, tc, t['kernel_us'], t['launches'], t['dominant_name'], t['dominant_us'] / t['dominant_launches'],
