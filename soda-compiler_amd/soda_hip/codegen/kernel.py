@@ -19,10 +19,14 @@ import subprocess
 import tempfile
 
 from .. import __version__
-from . import kernel_common, kernel_stage, kernel_stream2d, kernel_stream3d
+from . import (kernel_common, kernel_stage, kernel_stream2d, kernel_stream2d_wp,
+               kernel_stream3d)
 from . import spec as specmod
 
 DEFAULT_MAX_DEPTH = 12
+# wavefronts per strip for deep fused kernels (0/1 = single-wave form only)
+WAVE_GROUPS = 0
+WAVE_PIPELINE_MIN_DEPTH = 8
 
 HIPCC_FLAGS = ['-x', 'hip', '--offload-arch=gfx950', '--cuda-device-only',
                '--no-gpu-bundle-output', '-O3', '-ffp-contract=off',
@@ -96,7 +100,8 @@ def fused_depths(spec, max_depth):
 
 
 def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
-             fused=True, depths=None, inline=True, **fused_options):
+             fused=True, depths=None, inline=True, wave_groups=None,
+             **fused_options):
   """Returns (kernel text, kernel table).  `depths` overrides the default set
   of fused depths (depth 1 is always included: the scheduler needs it)."""
   max_depth = DEFAULT_MAX_DEPTH if max_depth is None else max_depth
@@ -120,10 +125,24 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
       wanted = sorted(set([1] + [d for d in depths if len(wanted) > 1 or d == 1]))
     for depth in wanted:
       try:
-        ftext, entry = kernel_stream2d.emit(
-            spec, depth, cols=cols if cols else default_cols(spec),
-            chunk_rows=chunk_rows or 256,
-            prefetch=3 if prefetch is None else prefetch, **fused_options)
+        ftext = None
+        groups = WAVE_GROUPS if wave_groups is None else wave_groups
+        if groups > 1 and depth >= WAVE_PIPELINE_MIN_DEPTH:
+          # deep chains: one wavefront per group of levels (kernel_stream2d_wp)
+          try:
+            ftext, entry = kernel_stream2d_wp.emit(
+                spec, depth, cols=cols if cols else default_cols(spec),
+                chunk_rows=chunk_rows or 256,
+                prefetch=3 if prefetch is None else prefetch, groups=groups,
+                **{k: v for k, v in fused_options.items()
+                   if k in ('skip_fill', 'vgpr_budget', 'max_period')})
+          except kernel_stream2d.NotFusable as e:
+            notes.append('depth %d not wave-pipelined: %s' % (depth, e))
+        if ftext is None:
+          ftext, entry = kernel_stream2d.emit(
+              spec, depth, cols=cols if cols else default_cols(spec),
+              chunk_rows=chunk_rows or 256,
+              prefetch=3 if prefetch is None else prefetch, **fused_options)
       except kernel_stream2d.NotFusable as e:
         notes.append('depth %d not fused: %s' % (depth, e))
         continue

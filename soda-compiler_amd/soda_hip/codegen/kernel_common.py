@@ -133,6 +133,12 @@ struct soda_hip_args {
   i64 param[4];
 };
 
+// workgroup barrier that also orders LDS traffic (what __syncthreads() is)
+DEV void soda_block_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 DEV int lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }

@@ -1,0 +1,337 @@
+"""Fused 2-D kernels, wave-pipelined form: the chain of stage instances of one
+strip is cut into G consecutive groups and each group runs on its OWN wavefront
+of the workgroup; group g hands the newest row of its last instance to group g+1
+through a two-slot LDS buffer, one `s_barrier` per streamed row.
+
+Why: in the single-wave form (kernel_stream2d) a wavefront keeps the windows of
+ALL `depth` levels, ~200 VGPRs at depth 12, so only two waves fit a SIMD and the
+VALU issues at ~65 % of its peak (measured: 83 of 128 lane-ops/clk/CU at two
+waves per SIMD, 100 at four, 113 at eight).  Here a wavefront keeps depth/G
+levels (~70 VGPRs at depth 12, G = 4), six to seven waves fit, and the same
+arithmetic issues faster.  This is the reference's own structure one level up:
+SODA chains compute modules with FIFOs (reference src/soda/dataflow.py:122-346);
+the modules are wavefronts and the FIFOs are LDS rows.
+
+Everything else is as in kernel_stream2d: lane l holds C consecutive columns,
+x-neighbours by DPP wave shifts, windows rotated by unrolling, overlapped
+strips/chunks, run-time chunk length.  A hand-off costs each side one 16-byte
+LDS access per row; the barrier keeps the G wavefronts of a strip in lock step
+(they do equal work by construction).
+
+Scope: chains in which every group reads only itself and the LAST instance of
+the previous group (jacobi2d, seidel2d, blur ...); other programs use the
+single-wave form.
+"""
+import math
+
+from . import spec as specmod
+from .kernel_common import builtin_type, device_expr, tensor_index
+from .kernel_stream2d import LANES, Instance, NotFusable, geometry, kernel_name
+
+
+def build_groups(spec, depth, prefetch, groups):
+  if spec['dim'] != 2:
+    raise NotFusable('2-D programs only')
+  if len(spec['outputs']) != 1 or len(spec['inputs']) != 1:
+    raise NotFusable('one input, one output')
+  types = specmod.tensor_c_types(spec)
+  if len({specmod.ELEM_SIZE[t] for t in types.values()}) != 1:
+    raise NotFusable('mixed element widths')
+  in_name = spec['inputs'][0]['name']
+  source = Instance('in_%s' % in_name, in_name, 0, types[in_name])
+  source.role, source.group = 'global_in', 0
+  stages = []
+  current = {in_name: source}
+  for it in range(depth):
+    for stage in spec['stages']:
+      inst = Instance('k%d_%s' % (it, stage['name']), stage['name'], it,
+                      stage['c_type'], stage)
+      inst.role = 'compute'
+      for tensor, rel in stage['loads']:
+        inst.reads.append((current[tensor], tuple(rel), tensor))
+      stages.append(inst)
+      current[stage['name']] = inst
+    current[in_name] = current[spec['outputs'][0]]
+  final = current[spec['outputs'][0]]
+  final.final = True
+  if len(stages) < groups:
+    raise NotFusable('%d stage instance(s) cannot feed %d wavefronts'
+                     % (len(stages), groups))
+  # contiguous groups of (nearly) equal size: equal VALU work per wavefront
+  bounds = [round(i * len(stages) / groups) for i in range(groups + 1)]
+  for g in range(groups):
+    for inst in stages[bounds[g]:bounds[g + 1]]:
+      inst.group = g
+  last_of = [stages[bounds[g + 1] - 1] for g in range(groups)]
+  # consumer-side copies of the hand-off instances
+  copies = {}
+  for g in range(1, groups):
+    src = last_of[g - 1]
+    copy = Instance('h%d_%s' % (g, src.ident), src.tensor, src.iteration, src.c_type)
+    copy.role, copy.group, copy.origin = 'lds_in', g, src
+    src.role = 'lds_out'
+    src.handoff = g - 1
+    copy.handoff = g - 1
+    copies[id(src)] = copy
+  for inst in stages:
+    reads = []
+    for src, rel, name in inst.reads:
+      if src is source:
+        if inst.group != 0:
+          raise NotFusable('%s reads the program input from group %d'
+                           % (inst.ident, inst.group))
+      elif src.group != inst.group:
+        if src is not last_of[inst.group - 1] or src.group != inst.group - 1:
+          raise NotFusable('%s reads %s across wavefront groups'
+                           % (inst.ident, src.ident))
+        src = copies[id(src)]
+      reads.append((src, rel, name))
+    inst.reads = reads
+  # lags, in execution order; a hand-off arrives one step after it was produced
+  source.lag = 0
+  for inst in stages:
+    if id(inst) in copies and False:
+      pass
+    lag = None
+    for src, rel, _ in inst.reads:
+      if src.role == 'lds_in':
+        src.lag = src.origin.lag + 1
+      v = src.lag + rel[1] + (prefetch if src is source else 0)
+      lag = v if lag is None else max(lag, v)
+    inst.lag = lag
+  everything = [source] + stages + list(copies.values())
+  for inst in stages:
+    for src, rel, _ in inst.reads:
+      src.keep = max(src.keep, inst.lag - rel[1] - src.lag + 1)
+  for inst in stages:
+    if inst.role == 'compute' and not inst.final and inst.keep == 0:
+      raise NotFusable('stage %s is never read' % inst.tensor)
+  per_wave = []
+  for g in range(groups):
+    mine = [source] if g == 0 else [copies[id(last_of[g - 1])]]
+    mine += stages[bounds[g]:bounds[g + 1]]
+    per_wave.append(mine)
+  return everything, per_wave, final
+
+
+def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
+         max_period=12, vgpr_budget=120, skip_fill=1):
+  """Returns (text, kernel table entry)."""
+  types = specmod.tensor_c_types(spec)
+  index = tensor_index(spec)
+  in_type = spec['inputs'][0]['c_type']
+  out_name = spec['outputs'][0]
+  elem = specmod.ELEM_SIZE[in_type]
+  if cols is None:
+    cols = max(1, 16 // elem)
+  C = cols
+  everything, per_wave, final = build_groups(spec, depth, prefetch, groups)
+  geo = geometry(spec, depth, C, chunk_rows)
+  for inst in everything:
+    for src, rel, _ in inst.reads:
+      if abs(rel[0]) > C:
+        raise NotFusable('x offset %d exceeds the %d columns a lane holds'
+                         % (rel[0], C))
+  # one rotation period for the whole workgroup (the barrier count per loop
+  # trip must be the same in every wavefront); even, for the two LDS slots
+  best = None
+  for candidate in range(2, max_period + 1, 2):
+    if max(i.keep for i in everything) > candidate:
+      continue
+    divisors = [d for d in range(1, candidate + 1) if candidate % d == 0]
+    padded = [min(d for d in divisors if d >= i.keep) if i.keep else 0
+              for i in everything]
+    cost = (sum(padded), candidate)
+    if best is None or cost < best[0]:
+      best = (cost, candidate, padded)
+  if best is None:
+    raise NotFusable('windows exceed the rotation period limit')
+  period = best[1]
+  for inst, keep in zip(everything, best[2]):
+    inst.keep = keep
+  per_elem = max(1, elem // 4)
+  est_vgprs = max(sum(i.keep for i in mine) for mine in per_wave) * C * per_elem + \
+      4 * C + 20
+  if est_vgprs > vgpr_budget:
+    raise NotFusable('a wavefront would need about %d VGPRs (budget %d)'
+                     % (est_vgprs, vgpr_budget))
+  # first step at which an instance can matter (see kernel_stream2d.emit)
+  below = {id(final): 0}
+  order = [i for mine in per_wave for i in mine]
+  for inst in reversed(order):
+    need = below.get(id(inst))
+    if need is None:
+      continue
+    if inst.role == 'lds_in':
+      below[id(inst.origin)] = max(below.get(id(inst.origin), -10**9), need)
+    for src, rel, _ in inst.reads:
+      below[id(src)] = max(below.get(id(src), -10**9), need - rel[1])
+  for inst in everything:
+    inst.first_step = max(0, inst.lag + geo['y_lo'] - below.get(id(inst), 0))
+  name = kernel_name(spec, depth)
+  L = final.lag
+  T_in = builtin_type(in_type)
+  T_out = builtin_type(types[out_name])
+  vec = 'vec_%s' % name
+  o = []
+  line = o.append
+  line('// fused depth-%d kernel, wave-pipelined: %d wavefronts per strip, rotation '
+       'period %d,' % (depth, groups, period))
+  line('// strip = %d columns (%d out + halo %d/%d), prefetch %d rows, ~%d VGPRs'
+       % (LANES * C, geo['w_out'], geo['halo_lo'], geo['halo_hi'], prefetch,
+          est_vgprs))
+  for g, mine in enumerate(per_wave):
+    for inst in mine:
+      line('//   wave %d  %-20s lag %2d keep %2d  %s' % (
+          g, inst.ident, inst.lag, inst.keep,
+          '-> HBM' if inst.final else inst.role))
+  line('typedef %s %s __attribute__((ext_vector_type(%d), aligned(%d)));'
+       % (T_in, vec, C, elem))
+  line('typedef %s %s_lds __attribute__((ext_vector_type(%d), aligned(%d)));'
+       % (T_in, vec, C, C * elem))
+
+  def slot(inst, u, back):
+    return (u - back) % inst.keep
+
+  def operand(reader, src, rel, u, c):
+    back = reader.lag - src.lag - rel[1]
+    assert 0 <= back < src.keep, (reader.ident, src.ident, rel, back, src.keep)
+    row = '%s[%d]' % (src.ident, slot(src, u, back))
+    j = c + rel[0]
+    if 0 <= j < C:
+      return '%s[%d]' % (row, j)
+    if j < 0:
+      return 'from_lane_below(%s[%d])' % (row, C + j)
+    return 'from_lane_above(%s[%d])' % (row, j - C)
+
+  def emit_body(mine, guarded):
+    for u in range(period):
+      line('      {  // unrolled step %d' % u)
+      for inst in mine:
+        if inst.role == 'global_in':
+          s = slot(inst, u, 0)
+          line('        { i64 row = head + %d; if (row > H - 1) row = H - 1;' % u)
+          line('          const %s* p = g_in + row * W + x;' % T_in)
+          line('          if (INTERIOR) { const %s v = *(const %s*)p;%s }' % (
+              vec, vec, ''.join(' %s[%d][%d] = v[%d];' % (inst.ident, s, c, c)
+                                for c in range(C))))
+          line('          else {%s } }' % ''.join(
+              ' %s[%d][%d] = (x + %d >= 0 && x + %d < W) ? p[%d] : (%s)0;'
+              % (inst.ident, s, c, c, c, c, T_in) for c in range(C)))
+          continue
+        if inst.role == 'lds_in':
+          s = slot(inst, u, 0)
+          # written by the previous wavefront one step ago: the other slot
+          line('        { const %s_lds v = *(const %s_lds*)&handoff[%d][%d][lane * %d];%s }'
+               % (vec, vec, inst.handoff, (u + 1) % 2, C, ''.join(
+                   ' %s[%d][%d] = v[%d];' % (inst.ident, s, c, c) for c in range(C))))
+          continue
+        stage = inst.stage
+        ctype = builtin_type(inst.c_type)
+        by_name = {(n, rel): src for src, rel, n in inst.reads}
+        skip = guarded and inst.first_step > u
+        if skip:
+          line('        if (n + %d >= %d) {' % (u, inst.first_step))
+        direct = inst.keep == 0
+        if direct:
+          line('        %s out_row[%d];' % (ctype, C))
+        for c in range(C):
+          def load(tensor, rel, u=u, c=c, inst=inst, by_name=by_name):
+            return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, c)
+          target = ('out_row[%d]' % c) if direct else \
+              '%s[%d][%d]' % (inst.ident, slot(inst, u, 0), c)
+          if stage['lets']:
+            line('        {')
+            for let in stage['lets']:
+              line('          const %s %s = %s;' % (
+                  builtin_type(let['c_type']), let['name'],
+                  specmod.substitute_loads(device_expr(let['expr']), load)))
+            line('          %s = %s;' % (target, specmod.substitute_loads(
+                device_expr(stage['expr']), load)))
+            line('        }')
+          else:
+            line('        %s = %s;' % (target, specmod.substitute_loads(
+                device_expr(stage['expr']), load)))
+        if inst.role == 'lds_out':
+          line('        { %s_lds v;%s *(%s_lds*)&handoff[%d][%d][lane * %d] = v; }' % (
+              vec, ''.join(' v[%d] = out_row[%d];' % (c, c) for c in range(C)),
+              vec, inst.handoff, u % 2, C))
+        if inst.final:
+          line('        { const i64 y = head + %d;' % (u - L))
+          line('          if (y >= y0 && y < y1) {')
+          line('            %s* q = g_out + y * W + x;' % T_out)
+          line('            if (x >= st_lo && x + %d <= st_hi) { %s v;%s *(%s*)q = v; }'
+               % (C, vec, ''.join(' v[%d] = out_row[%d];' % (c, c) for c in range(C)),
+                  vec))
+          line('            else {%s }' % ''.join(
+              ' if (x + %d >= st_lo && x + %d < st_hi) q[%d] = out_row[%d];'
+              % (c, c, c, c) for c in range(C)))
+          line('          } }')
+        if skip:
+          line('        }')
+      line('      }')
+      line('      soda_block_barrier();')
+
+  line('template <bool INTERIOR>')
+  line('DEV void %s_strip(const soda_hip_args& a, const i64 xs, const i64 x, '
+       'const i64 y0, const i64 y1, const int wave, const int lane,' % name)
+  line('    %s (*handoff)[2][%d]) {' % (T_in, LANES * C))
+  line('  const i64 W = a.dims[0], H = a.dims[1];')
+  line('  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];')
+  line('  const i64 st_hi = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];'
+       % (geo['w_out'], geo['w_out']))
+  line('  const %s* __restrict__ g_in = (const %s*)a.tensor[%d];'
+       % (T_in, T_in, index[spec['inputs'][0]['name']]))
+  line('  %s* __restrict__ g_out = (%s*)a.tensor[%d];' % (T_out, T_out,
+                                                           index[out_name]))
+  line('  (void)g_in; (void)g_out; (void)st_lo; (void)st_hi; (void)W; (void)H;')
+  line('  const i64 steps = (y1 - y0) + %d;' % (L + geo['y_lo']))
+  prologue_steps = max(i.first_step for i in everything)
+  prologue_steps = -(-prologue_steps // period) * period if skip_fill else 0
+  for g, mine in enumerate(per_wave):
+    line('  %sif (wave == %d) {' % ('' if g == 0 else 'else ', g))
+    for inst in mine:
+      if inst.keep:
+        line('    %s %s[%d][%d];' % (builtin_type(inst.c_type), inst.ident,
+                                     inst.keep, C))
+        for r in range(inst.keep):
+          line('    ' + ' '.join('%s[%d][%d] = 0;' % (inst.ident, r, c)
+                                 for c in range(C)))
+    line('    i64 head = y0 - %d;' % geo['y_lo'])
+    line('    i64 n = 0;')
+    if prologue_steps:
+      line('    for (; n < %d && n < steps; n += %d, head += %d) {'
+           % (prologue_steps, period, period))
+      emit_body(mine, True)
+      line('    }')
+    line('    for (; n < steps; n += %d, head += %d) {' % (period, period))
+    emit_body(mine, False)
+    line('    }')
+    line('  }')
+  line('}')
+  line('')
+  line('GLOBAL WG_SIZE(%d) void %s(soda_hip_args a) {' % (groups * LANES, name))
+  line('  __attribute__((shared)) %s handoff[%d][2][%d];' % (
+      T_in, max(1, groups - 1), LANES * C))
+  line('  const int lane = lane_id();')
+  line('  const int wave = __builtin_amdgcn_readfirstlane('
+       '__builtin_amdgcn_workitem_id_x() >> 6);')
+  line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % C)
+  line('  const i64 xs = x_origin + (i64)__builtin_amdgcn_workgroup_id_x() * %d;'
+       % geo['w_out'])
+  line('  if (xs >= a.box_hi[0]) return;')
+  line('  const i64 x = xs - %d + lane * %d;' % (geo['halo_lo'], C))
+  line('  const i64 chunk = a.param[0] > 0 ? a.param[0] : %d;' % chunk_rows)
+  line('  const i64 y0 = a.box_lo[1] + (i64)__builtin_amdgcn_workgroup_id_y() * chunk;')
+  line('  const i64 y1 = y0 + chunk < a.box_hi[1] ? y0 + chunk : a.box_hi[1];')
+  line('  const bool interior = xs - %d >= 0 && xs - %d + %d <= a.dims[0];'
+       % (geo['halo_lo'], geo['halo_lo'], LANES * C))
+  line('  if (interior) %s_strip<true>(a, xs, x, y0, y1, wave, lane, handoff);' % name)
+  line('  else %s_strip<false>(a, xs, x, y0, y1, wave, lane, handoff);' % name)
+  line('}')
+  entry = dict(name=name, kind='fused', depth=depth, stage=-1,
+               block=[groups * LANES, 1, 1],
+               tile=[geo['w_out'] - C, chunk_rows, 1, 1],
+               fill_rows=L + geo['y_lo'], cols=C, prefetch=prefetch, period=period,
+               est_vgprs=est_vgprs, groups=groups, w_out=geo['w_out'])
+  return '\n'.join(o) + '\n', entry

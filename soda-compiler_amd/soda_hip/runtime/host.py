@@ -101,6 +101,8 @@ class Blob:
   def from_source(cls, text, arch=None, options=('-fno-slp-vectorize', '-fwrapv')):
     from ..codegen.kernel import flags_from_text
     options = tuple(options) + tuple(flags_from_text(text))
+    if os.environ.get('SODA_HIP_SLP'):      # tuning: let the SLP vectoriser pack
+      options = tuple(o for o in options if o != '-fno-slp-vectorize')
     h = ctypes.c_void_p()
     opts = (ctypes.c_char_p * len(options))(*[o.encode() for o in options])
     capi.check(capi.lib().soda_hip_module_compile(

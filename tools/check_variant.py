@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Parity of a fused-kernel generator variant against the oracle on the GPU box.
+usage: check_variant.py app 'key=value,...' (generate() options)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd'), os.path.join(ROOT, 'tests')]
+import numpy as np
+import torch  # noqa: F401
+from soda_hip import frontend
+from soda_hip.codegen import kernel, spec as specmod
+from soda_hip.runtime import host
+from oracle import soda_oracle
+app = sys.argv[1]
+opts = {k: int(v) for k, v in (kv.split('=') for kv in sys.argv[2].split(','))} if len(sys.argv) > 2 and sys.argv[2] else {}
+ok = True
+for iterate, shape in ((12, (300, 1100)), (25, (257, 1021)), (13, (100, 2049)), (37, (611, 700)), (8, (64, 64))):
+  st = frontend.load(os.path.join(ROOT, 'tests', 'samples', app + '.soda'), iterate=iterate)
+  spec = specmod.spec_from_stencil(st)
+  text, table = kernel.generate(spec, **opts)
+  prog = host.open_program(source=text, spec=spec)
+  rng = np.random.default_rng(3)
+  dt = prog.in_dtypes[0]
+  a = rng.random(shape, dtype=np.float32).astype(dt) if dt.kind == 'f' else rng.integers(0, 65536, size=shape).astype(dt)
+  got = prog.run_numpy([a], iterate=iterate)[0]
+  orc = soda_oracle.Oracle(spec)
+  want = orc.run([a], iterate=iterate)[spec['outputs'][0]]
+  sl = orc.valid_slices(tuple(reversed(shape)), iterate)
+  bad = int((got[sl] != want[sl]).sum())
+  print(app, opts, 'iterate', iterate, shape, [k['name'] + ('/wp' if k.get('groups') else '') for k in table if k['kind'] == 'fused'], 'bad', bad, 'of', want[sl].size)
+  ok &= bad == 0
+  prog.close(); prog.blob.unload()
+sys.exit(0 if ok else 1)

@@ -25,7 +25,9 @@ for variant in sys.argv[4:]:
   extra = dict(kv.split('=') for kv in parts[4:])
   extra = {k: int(v) for k, v in extra.items()}
   t0 = time.time()
-  text, table = kernel.generate(spec, depths=[depth], cols=cols, chunk_rows=chunk, prefetch=pf, vgpr_budget=400, **extra)
+  if 'wave_groups' not in extra:
+    extra.setdefault('vgpr_budget', 400)
+  text, table = kernel.generate(spec, depths=[depth], cols=cols, chunk_rows=chunk, prefetch=pf, **extra)
   try:
     prog = host.open_program(source=text, spec=spec)
   except Exception as e:
