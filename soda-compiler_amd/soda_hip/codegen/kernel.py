@@ -24,9 +24,19 @@ from . import (kernel_common, kernel_stage, kernel_stream2d, kernel_stream2d_wp,
 from . import spec as specmod
 
 DEFAULT_MAX_DEPTH = 12
-# wavefronts per strip for deep fused kernels (0/1 = single-wave form only)
-WAVE_GROUPS = 0
-WAVE_PIPELINE_MIN_DEPTH = 8
+# Wavefronts per strip for deep fused 2-D kernels: 0 = single-wave form only,
+# N > 1 = always the wave-pipelined form (kernel_stream2d_wp), -1 = choose: the
+# wave-pipelined form (4 wavefronts, packed pairs when the program allows) where
+# the single-wave form would need more than AUTO_WP_VGPRS registers or does not
+# fit at all.  Measured on MI355X at 16384x16384 (tools/tune.py): jacobi2d depth
+# 12 (188 VGPRs) single-wave 543 us vs 545-570 us pipelined; seidel2d depth 12
+# (236 VGPRs) 684 us vs 588 us; blur depth 8 (single-wave impossible, depth 4 is
+# its limit) 4402 vs 3499 Gcell/s.
+WAVE_GROUPS = -1
+AUTO_WP_VGPRS = 200
+AUTO_WP_GROUPS = 4
+AUTO_WP_BUDGET = 200
+WAVE_PIPELINE_MIN_DEPTH = 4
 
 HIPCC_FLAGS = ['-x', 'hip', '--offload-arch=gfx950', '--cuda-device-only',
                '--no-gpu-bundle-output', '-O3', '-ffp-contract=off',
@@ -124,28 +134,43 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
     if depths is not None:
       wanted = sorted(set([1] + [d for d in depths if len(wanted) > 1 or d == 1]))
     for depth in wanted:
-      try:
-        ftext = None
-        groups = WAVE_GROUPS if wave_groups is None else wave_groups
-        if groups > 1 and depth >= WAVE_PIPELINE_MIN_DEPTH:
-          # deep chains: one wavefront per group of levels (kernel_stream2d_wp)
-          try:
-            ftext, entry = kernel_stream2d_wp.emit(
-                spec, depth, cols=cols if cols else default_cols(spec),
-                chunk_rows=chunk_rows or 256,
-                prefetch=3 if prefetch is None else prefetch, groups=groups,
-                **{k: v for k, v in fused_options.items()
-                   if k in ('skip_fill', 'vgpr_budget', 'max_period')})
-          except kernel_stream2d.NotFusable as e:
-            notes.append('depth %d not wave-pipelined: %s' % (depth, e))
-        if ftext is None:
-          ftext, entry = kernel_stream2d.emit(
-              spec, depth, cols=cols if cols else default_cols(spec),
-              chunk_rows=chunk_rows or 256,
-              prefetch=3 if prefetch is None else prefetch, **fused_options)
-      except kernel_stream2d.NotFusable as e:
-        notes.append('depth %d not fused: %s' % (depth, e))
+      groups = WAVE_GROUPS if wave_groups is None else wave_groups
+      common = dict(cols=cols if cols else default_cols(spec),
+                    chunk_rows=chunk_rows or 256,
+                    prefetch=3 if prefetch is None else prefetch)
+      single = piped = None
+      if groups <= 1 or depth < WAVE_PIPELINE_MIN_DEPTH or groups == -1:
+        try:
+          single = kernel_stream2d.emit(
+              spec, depth, **common,
+              **{k: v for k, v in fused_options.items() if k != 'pairs'})
+        except kernel_stream2d.NotFusable as e:
+          notes.append('depth %d not fused: %s' % (depth, e))
+      want_piped = depth >= WAVE_PIPELINE_MIN_DEPTH and (
+          groups > 1 or (groups == -1 and (
+              single is None or single[1]['est_vgprs'] > AUTO_WP_VGPRS)))
+      if want_piped:
+        options = {k: v for k, v in fused_options.items()
+                   if k in ('skip_fill', 'vgpr_budget', 'max_period', 'pairs')}
+        if groups == -1:
+          options.setdefault('vgpr_budget', AUTO_WP_BUDGET)
+          options.setdefault('pairs', int(kernel_stream2d_wp.packable(spec)))
+        try:
+          piped = kernel_stream2d_wp.emit(
+              spec, depth, groups=AUTO_WP_GROUPS if groups == -1 else groups,
+              **common, **options)
+        except kernel_stream2d.NotFusable as e:
+          notes.append('depth %d not wave-pipelined: %s' % (depth, e))
+          if single is None and groups > 1:
+            try:
+              single = kernel_stream2d.emit(
+                  spec, depth, **common,
+                  **{k: v for k, v in fused_options.items() if k != 'pairs'})
+            except kernel_stream2d.NotFusable as e2:
+              notes.append('depth %d not fused: %s' % (depth, e2))
+      if piped is None and single is None:
         continue
+      ftext, entry = piped if piped is not None else single
       parts.append(ftext)
       table.append(entry)
   if fused and spec['dim'] == 3:

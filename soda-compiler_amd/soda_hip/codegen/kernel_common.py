@@ -145,10 +145,10 @@ DEV int lane_id() {
 // value of `v` in lane-1 / lane+1 of the 64-lane wavefront (DPP wave shifts;
 // the lane with no such neighbour receives 0)
 DEV int dpp_from_below(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
 }
 DEV int dpp_from_above(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 }
 template <typename T, bool BELOW> DEV T lane_neighbour(T v) {
   if constexpr (sizeof(T) == 4) {

@@ -3,14 +3,21 @@ strip is cut into G consecutive groups and each group runs on its OWN wavefront
 of the workgroup; group g hands the newest row of its last instance to group g+1
 through a two-slot LDS buffer, one `s_barrier` per streamed row.
 
-Why: in the single-wave form (kernel_stream2d) a wavefront keeps the windows of
-ALL `depth` levels, ~200 VGPRs at depth 12, so only two waves fit a SIMD and the
-VALU issues at ~65 % of its peak (measured: 83 of 128 lane-ops/clk/CU at two
-waves per SIMD, 100 at four, 113 at eight).  Here a wavefront keeps depth/G
-levels (~70 VGPRs at depth 12, G = 4), six to seven waves fit, and the same
-arithmetic issues faster.  This is the reference's own structure one level up:
-SODA chains compute modules with FIFOs (reference src/soda/dataflow.py:122-346);
-the modules are wavefronts and the FIFOs are LDS rows.
+Why it exists: in the single-wave form (kernel_stream2d) a wavefront keeps the
+windows of ALL `depth` levels, ~200 VGPRs at depth 12, so two waves fit a SIMD.
+Here a wavefront keeps depth/G levels (~70 VGPRs at depth 12, G = 4) and six to
+seven waves fit.  This is the reference's own structure one level up: SODA chains
+compute modules with FIFOs (reference src/soda/dataflow.py:122-346); the modules
+are wavefronts and the FIFOs are LDS rows.
+
+Status: EXPERIMENTAL, off by default (kernel.WAVE_GROUPS = 0).  Measured on
+MI355X, jacobi2d 16384x16384, depth 12 (tools/tune.py): single-wave 543-555 us,
+this form 570-590 us, this form with packed pairs (below) 543-570 us.  The
+single-wave kernel already issues ~92 % of what the VALU sustains for its
+instruction mix at two waves per SIMD (tools/valubench.hip: 42.6 T lane-ops/s for
+the scalar jacobi row, 50-56 T for the packed one at 2-3 waves per SIMD), so the
+extra occupancy buys nothing and the barrier per row costs a little.  Both forms
+are bit-exact against the oracle (tools/check_variant.py).
 
 Everything else is as in kernel_stream2d: lane l holds C consecutive columns,
 x-neighbours by DPP wave shifts, windows rotated by unrolling, overlapped
@@ -23,6 +30,7 @@ the previous group (jacobi2d, seidel2d, blur ...); other programs use the
 single-wave form.
 """
 import math
+import re
 
 from . import spec as specmod
 from .kernel_common import builtin_type, device_expr, tensor_index
@@ -114,9 +122,36 @@ def build_groups(spec, depth, prefetch, groups):
   return everything, per_wave, final
 
 
+PLAIN_FLOAT_EXPR = re.compile(
+    r'^(?:\{[^}]*\}|(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?f|\d+|[-+*/() ])*$')
+
+
+def packable(spec):
+  """True when every value of the program is a float and every expression is
+  made of loads, + - * /, float-suffixed or integer literals only: such a program
+  computes the same bits on <2 x float> operands (v_pk_add_f32 / v_pk_mul_f32 are
+  IEEE like their scalar forms; a double literal would promote a scalar
+  expression but not a vector one, so it disqualifies)."""
+  if any(t != 'float' for t in specmod.tensor_c_types(spec).values()):
+    return False
+  for stage in spec['stages']:
+    if stage['lets']:
+      return False
+    if not PLAIN_FLOAT_EXPR.match(device_expr(stage['expr'])):
+      return False
+  return True
+
+
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
-         max_period=12, vgpr_budget=120, skip_fill=1):
-  """Returns (text, kernel table entry)."""
+         max_period=12, vgpr_budget=120, skip_fill=1, pairs=0):
+  """Returns (text, kernel table entry).
+
+  pairs=1 (float programs, see packable()): a wavefront streams TWO adjacent
+  strips at once, element c of strip A and element c of strip B sharing one
+  64-bit register pair, so that every add and multiply is a packed
+  v_pk_add_f32 / v_pk_mul_f32 (two results per issue slot: measured 68 T
+  lane-ops/s against 37.5 T for the scalar forms, tools/microbench.hip).  Both
+  halves have the same neighbours, hence no operand ever straddles a pair."""
   types = specmod.tensor_c_types(spec)
   index = tensor_index(spec)
   in_type = spec['inputs'][0]['c_type']
@@ -125,6 +160,11 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   if cols is None:
     cols = max(1, 16 // elem)
   C = cols
+  if pairs and not packable(spec):
+    raise NotFusable('packed form: float programs of + - * / only')
+  if pairs and (C * elem) % 16:
+    raise NotFusable('packed form: whole 16-byte vectors per lane')
+  P = 2 if pairs else 1
   everything, per_wave, final = build_groups(spec, depth, prefetch, groups)
   geo = geometry(spec, depth, C, chunk_rows)
   for inst in everything:
@@ -150,8 +190,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   for inst, keep in zip(everything, best[2]):
     inst.keep = keep
   per_elem = max(1, elem // 4)
-  est_vgprs = max(sum(i.keep for i in mine) for mine in per_wave) * C * per_elem + \
-      4 * C + 20
+  est_vgprs = max(sum(i.keep for i in mine) for mine in per_wave) * C * per_elem * P + \
+      4 * C * P + 20
   if est_vgprs > vgpr_budget:
     raise NotFusable('a wavefront would need about %d VGPRs (budget %d)'
                      % (est_vgprs, vgpr_budget))
@@ -189,6 +229,12 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
        % (T_in, vec, C, elem))
   line('typedef %s %s_lds __attribute__((ext_vector_type(%d), aligned(%d)));'
        % (T_in, vec, C, C * elem))
+  if pairs:
+    line('typedef float pk2 __attribute__((ext_vector_type(2)));')
+    line('typedef float soda_f4 __attribute__((ext_vector_type(4)));')
+  # LDS hand-off rows: 16-byte pieces, piece q of lane l at [q][l] (conflict-free)
+  pieces = C * P * elem // 16 if pairs else 1
+  per_piece = C * P // pieces
 
   def slot(inst, u, back):
     return (u - back) % inst.keep
@@ -212,6 +258,17 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
           s = slot(inst, u, 0)
           line('        { i64 row = head + %d; if (row > H - 1) row = H - 1;' % u)
           line('          const %s* p = g_in + row * W + x;' % T_in)
+          if pairs:
+            line('          if (INTERIOR) { const %s va = *(const %s*)p, vb = *(const %s*)'
+                 '(p + %d);%s }' % (vec, vec, vec, geo['w_out'], ''.join(
+                     ' %s[%d][%d] = pk2{va[%d], vb[%d]};' % (inst.ident, s, c, c, c)
+                     for c in range(C))))
+            line('          else {%s } }' % ''.join(
+                ' %s[%d][%d] = pk2{(x + %d >= 0 && x + %d < W) ? p[%d] : 0.0f, '
+                '(x + %d >= 0 && x + %d < W) ? p[%d] : 0.0f};'
+                % (inst.ident, s, c, c, c, c, c + geo['w_out'], c + geo['w_out'],
+                   c + geo['w_out']) for c in range(C)))
+            continue
           line('          if (INTERIOR) { const %s v = *(const %s*)p;%s }' % (
               vec, vec, ''.join(' %s[%d][%d] = v[%d];' % (inst.ident, s, c, c)
                                 for c in range(C))))
@@ -222,12 +279,20 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
         if inst.role == 'lds_in':
           s = slot(inst, u, 0)
           # written by the previous wavefront one step ago: the other slot
+          if pairs:
+            for q in range(pieces):
+              line('        { const soda_f4 v = *(const soda_f4*)&handoff[%d][%d][%d][lane * 4];%s }'
+                   % (inst.handoff, (u + 1) % 2, q, ''.join(
+                       ' %s[%d][%d] = pk2{v[%d], v[%d]};' % (
+                           inst.ident, s, q * 2 + j, 2 * j, 2 * j + 1)
+                       for j in range(2))))
+            continue
           line('        { const %s_lds v = *(const %s_lds*)&handoff[%d][%d][lane * %d];%s }'
                % (vec, vec, inst.handoff, (u + 1) % 2, C, ''.join(
                    ' %s[%d][%d] = v[%d];' % (inst.ident, s, c, c) for c in range(C))))
           continue
         stage = inst.stage
-        ctype = builtin_type(inst.c_type)
+        ctype = 'pk2' if pairs else builtin_type(inst.c_type)
         by_name = {(n, rel): src for src, rel, n in inst.reads}
         skip = guarded and inst.first_step > u
         if skip:
@@ -252,7 +317,13 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
           else:
             line('        %s = %s;' % (target, specmod.substitute_loads(
                 device_expr(stage['expr']), load)))
-        if inst.role == 'lds_out':
+        if inst.role == 'lds_out' and pairs:
+          for q in range(pieces):
+            line('        { soda_f4 v;%s *(soda_f4*)&handoff[%d][%d][%d][lane * 4] = v; }' % (
+                ''.join(' v[%d] = out_row[%d][0]; v[%d] = out_row[%d][1];' % (
+                    2 * j, q * 2 + j, 2 * j + 1, q * 2 + j) for j in range(2)),
+                inst.handoff, u % 2, q))
+        elif inst.role == 'lds_out':
           line('        { %s_lds v;%s *(%s_lds*)&handoff[%d][%d][lane * %d] = v; }' % (
               vec, ''.join(' v[%d] = out_row[%d];' % (c, c) for c in range(C)),
               vec, inst.handoff, u % 2, C))
@@ -260,12 +331,18 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
           line('        { const i64 y = head + %d;' % (u - L))
           line('          if (y >= y0 && y < y1) {')
           line('            %s* q = g_out + y * W + x;' % T_out)
-          line('            if (x >= st_lo && x + %d <= st_hi) { %s v;%s *(%s*)q = v; }'
-               % (C, vec, ''.join(' v[%d] = out_row[%d];' % (c, c) for c in range(C)),
-                  vec))
-          line('            else {%s }' % ''.join(
-              ' if (x + %d >= st_lo && x + %d < st_hi) q[%d] = out_row[%d];'
-              % (c, c, c, c) for c in range(C)))
+          for half in range(P):
+            sel = '[%d]' % half if pairs else ''
+            sfx = 'b' if half else ''
+            off = geo['w_out'] * half
+            line('            if (x + %d >= st_lo%s && x + %d <= st_hi%s) { %s v;%s '
+                 '*(%s*)(q + %d) = v; }'
+                 % (off, sfx, off + C, sfx, vec, ''.join(
+                     ' v[%d] = out_row[%d]%s;' % (c, c, sel) for c in range(C)),
+                    vec, off))
+            line('            else {%s }' % ''.join(
+                ' if (x + %d >= st_lo%s && x + %d < st_hi%s) q[%d] = out_row[%d]%s;'
+                % (c + off, sfx, c + off, sfx, c + off, c, sel) for c in range(C)))
           line('          } }')
         if skip:
           line('        }')
@@ -275,11 +352,19 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   line('template <bool INTERIOR>')
   line('DEV void %s_strip(const soda_hip_args& a, const i64 xs, const i64 x, '
        'const i64 y0, const i64 y1, const int wave, const int lane,' % name)
-  line('    %s (*handoff)[2][%d]) {' % (T_in, LANES * C))
+  if pairs:
+    line('    float (*handoff)[2][%d][%d]) {' % (pieces, LANES * 4))
+  else:
+    line('    %s (*handoff)[2][%d]) {' % (T_in, LANES * C))
   line('  const i64 W = a.dims[0], H = a.dims[1];')
   line('  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];')
   line('  const i64 st_hi = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];'
        % (geo['w_out'], geo['w_out']))
+  if pairs:   # the second strip starts where the first one ends
+    line('  const i64 st_lob = xs + %d;' % geo['w_out'])
+    line('  const i64 st_hib = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];'
+         % (2 * geo['w_out'], 2 * geo['w_out']))
+    line('  (void)st_lob; (void)st_hib;')
   line('  const %s* __restrict__ g_in = (const %s*)a.tensor[%d];'
        % (T_in, T_in, index[spec['inputs'][0]['name']]))
   line('  %s* __restrict__ g_out = (%s*)a.tensor[%d];' % (T_out, T_out,
@@ -292,10 +377,11 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
     line('  %sif (wave == %d) {' % ('' if g == 0 else 'else ', g))
     for inst in mine:
       if inst.keep:
-        line('    %s %s[%d][%d];' % (builtin_type(inst.c_type), inst.ident,
-                                     inst.keep, C))
+        line('    %s %s[%d][%d];' % ('pk2' if pairs else builtin_type(inst.c_type),
+                                     inst.ident, inst.keep, C))
         for r in range(inst.keep):
-          line('    ' + ' '.join('%s[%d][%d] = 0;' % (inst.ident, r, c)
+          line('    ' + ' '.join('%s[%d][%d] = %s;' % (
+              inst.ident, r, c, 'pk2{0.0f, 0.0f}' if pairs else '0')
                                  for c in range(C)))
     line('    i64 head = y0 - %d;' % geo['y_lo'])
     line('    i64 n = 0;')
@@ -311,27 +397,31 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   line('}')
   line('')
   line('GLOBAL WG_SIZE(%d) void %s(soda_hip_args a) {' % (groups * LANES, name))
-  line('  __attribute__((shared)) %s handoff[%d][2][%d];' % (
-      T_in, max(1, groups - 1), LANES * C))
+  if pairs:
+    line('  __attribute__((shared)) float handoff[%d][2][%d][%d];' % (
+        max(1, groups - 1), pieces, LANES * 4))
+  else:
+    line('  __attribute__((shared)) %s handoff[%d][2][%d];' % (
+        T_in, max(1, groups - 1), LANES * C))
   line('  const int lane = lane_id();')
   line('  const int wave = __builtin_amdgcn_readfirstlane('
        '__builtin_amdgcn_workitem_id_x() >> 6);')
   line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % C)
   line('  const i64 xs = x_origin + (i64)__builtin_amdgcn_workgroup_id_x() * %d;'
-       % geo['w_out'])
+       % (P * geo['w_out']))
   line('  if (xs >= a.box_hi[0]) return;')
   line('  const i64 x = xs - %d + lane * %d;' % (geo['halo_lo'], C))
   line('  const i64 chunk = a.param[0] > 0 ? a.param[0] : %d;' % chunk_rows)
   line('  const i64 y0 = a.box_lo[1] + (i64)__builtin_amdgcn_workgroup_id_y() * chunk;')
   line('  const i64 y1 = y0 + chunk < a.box_hi[1] ? y0 + chunk : a.box_hi[1];')
   line('  const bool interior = xs - %d >= 0 && xs - %d + %d <= a.dims[0];'
-       % (geo['halo_lo'], geo['halo_lo'], LANES * C))
+       % (geo['halo_lo'], geo['halo_lo'], LANES * C + (P - 1) * geo['w_out']))
   line('  if (interior) %s_strip<true>(a, xs, x, y0, y1, wave, lane, handoff);' % name)
   line('  else %s_strip<false>(a, xs, x, y0, y1, wave, lane, handoff);' % name)
   line('}')
   entry = dict(name=name, kind='fused', depth=depth, stage=-1,
                block=[groups * LANES, 1, 1],
-               tile=[geo['w_out'] - C, chunk_rows, 1, 1],
+               tile=[P * geo['w_out'] - C, chunk_rows, 1, 1], pairs=int(bool(pairs)),
                fill_rows=L + geo['y_lo'], cols=C, prefetch=prefetch, period=period,
                est_vgprs=est_vgprs, groups=groups, w_out=geo['w_out'])
   return '\n'.join(o) + '\n', entry

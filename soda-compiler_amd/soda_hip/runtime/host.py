@@ -103,6 +103,7 @@ class Blob:
     options = tuple(options) + tuple(flags_from_text(text))
     if os.environ.get('SODA_HIP_SLP'):      # tuning: let the SLP vectoriser pack
       options = tuple(o for o in options if o != '-fno-slp-vectorize')
+    options += tuple(os.environ.get('SODA_HIP_EXTRA_FLAGS', '').split())   # tuning
     h = ctypes.c_void_p()
     opts = (ctypes.c_char_p * len(options))(*[o.encode() for o in options])
     capi.check(capi.lib().soda_hip_module_compile(

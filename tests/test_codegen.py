@@ -105,6 +105,32 @@ def test_every_sample_compiles_for_gfx950(app, tmp_path):
   assert len(stages) == len(specmod.inline_pointwise(spec)['stages'])
 
 
+@pytest.mark.parametrize('options', [dict(wave_groups=4), dict(wave_groups=4, pairs=1,
+                                                                vgpr_budget=250)])
+def test_wave_pipelined_forms_compile(options, tmp_path):
+  """The experimental wave-pipelined form of the fused 2-D kernel (one wavefront
+  per group of levels, LDS hand-off) and its packed-pair variant build for
+  gfx950; the packed variant is refused for anything but plain float programs."""
+  from soda_hip.codegen import kernel_stream2d, kernel_stream2d_wp
+  spec = spec_of('jacobi2d', iterate=8)
+  text, table = kernel.generate(spec, depths=[8], **options)
+  fused = [k for k in table if k['kind'] == 'fused' and k['depth'] == 8]
+  assert fused and fused[0]['groups'] == 4 and fused[0]['block'] == [256, 1, 1]
+  assert fused[0]['pairs'] == options.get('pairs', 0)
+  if options.get('pairs'):
+    assert fused[0]['tile'][0] == 2 * fused[0]['w_out'] - fused[0]['cols']
+    assert 'pk2' in text
+  out = tmp_path / 'wp.hsaco'
+  kernel.compile_to_code_object(text, str(out))
+  assert open(out, 'rb').read(4) == b'\x7fELF'
+  assert kernel_stream2d_wp.packable(spec)
+  for app in ('blur', 'sobel2d', 'denoise2d'):
+    assert not kernel_stream2d_wp.packable(specmod.inline_pointwise(spec_of(app)))
+  with pytest.raises(kernel_stream2d.NotFusable):
+    kernel_stream2d_wp.emit(specmod.inline_pointwise(spec_of('blur', iterate=8)), 8,
+                            pairs=1)
+
+
 def test_pipeline_lags_match_the_reference_reuse_model():
   """jacobi2d: each level trails the previous by one row and keeps three rows
   (the reference's reuse chain for a 3-row window is 2 rows + 1)."""

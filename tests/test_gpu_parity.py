@@ -106,6 +106,32 @@ def test_jacobi2d_iterations_and_depths(iterate, max_depth):
   check('jacobi2d', inputs, iterate, max_depth)
 
 
+@pytest.mark.parametrize('app,options', [
+    ('jacobi2d', dict(wave_groups=4)),
+    ('jacobi2d', dict(wave_groups=4, pairs=1, vgpr_budget=250)),
+    ('jacobi2d', dict(wave_groups=2, pairs=1, vgpr_budget=250)),
+    ('seidel2d', dict(wave_groups=4, pairs=1, vgpr_budget=250)),
+    ('blur', dict(wave_groups=4, vgpr_budget=200))])
+def test_wave_pipelined_generator_forms(app, options):
+  """The experimental forms of the fused 2-D kernel (wavefront pipeline through
+  LDS; two strips packed into v_pk_*_f32 operands) produce the oracle's bits."""
+  from soda_hip.codegen import kernel, spec as specmod
+  from soda_hip.runtime import host
+  for iterate, shape in ((8, (130, 1300)), (19, (300, 2100)), (9, (64, 64))):
+    spec = gpu_util.load_spec(app, iterate=iterate)
+    text, table = kernel.generate(spec, **options)
+    assert any(k.get('groups') for k in table), [k['name'] for k in table]
+    prog = host.open_program(source=text, spec=spec)
+    inputs = gpu_util.random_inputs(spec, shape)
+    got = prog.run_numpy(inputs, iterate=iterate)[0]
+    orc = soda_oracle.Oracle(spec)
+    want = orc.run(inputs, iterate=iterate)[spec['outputs'][0]]
+    sl = orc.valid_slices(tuple(reversed(shape)), iterate)
+    assert np.array_equal(got[sl], want[sl], equal_nan=True), (app, options, iterate)
+    prog.close()
+    prog.blob.unload()
+
+
 @pytest.mark.parametrize('shape', [
     (64, 64), (65, 257), (100, 241), (257, 1021), (41, 2049), (600, 97)])
 def test_jacobi2d_ragged_shapes(shape):

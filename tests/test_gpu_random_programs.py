@@ -94,15 +94,11 @@ def random_program(rng, seed):
   return '\n'.join(lines) + '\n', dim, dtype, iterate
 
 
-@pytest.mark.parametrize('seed', range(int(os.environ.get('SODA_RANDOM_SEEDS', '40'))))
-def test_random_program(seed):
-  rng = np.random.default_rng(1000 + seed)
-  text, dim, dtype, iterate = random_program(rng, seed)
+def run_case(text, dim, iterate, seed, shape, rng):
   stencil = frontend.loads(text)
   spec = specmod.spec_from_stencil(stencil)
   src, table = kernel.generate(spec)
   prog = host.open_program(source=src, spec=spec)
-  shape = (41, 333) if dim == 2 else (19, 23, 150)
   inputs = []
   for t in spec['inputs']:
     dt = np.dtype(specmod.NUMPY_NAME[t['c_type']])
@@ -124,3 +120,26 @@ def test_random_program(seed):
         seed, max_depth, fused, text)
   prog.close()
   prog.blob.unload()
+  return table
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('SODA_RANDOM_SEEDS', '40'))))
+def test_random_program(seed):
+  rng = np.random.default_rng(1000 + seed)
+  text, dim, dtype, iterate = random_program(rng, seed)
+  run_case(text, dim, iterate, seed, (41, 333) if dim == 2 else (19, 23, 150), rng)
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('SODA_RANDOM_DEEP_SEEDS', '16'))))
+def test_random_program_many_iterations(seed):
+  """The same generator with `iterate` 8..14: deep fused kernels, among them
+  the wave-pipelined and packed forms the generator picks for chains that do not
+  fit one wavefront's registers."""
+  rng = np.random.default_rng(5000 + seed)
+  while True:
+    text, dim, dtype, iterate = random_program(rng, seed)
+    if dim == 2 and 'input %s: in1' % dtype not in text:
+      break
+  deep = int(rng.integers(8, 15))
+  text = text.replace('iterate: %d\n' % iterate, 'iterate: %d\n' % deep)
+  run_case(text, dim, deep, seed, (400, 700), rng)
