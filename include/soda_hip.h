@@ -147,7 +147,12 @@ typedef struct soda_hip_kernel {
   int32_t fill_rows; /* streaming kernels: extra outer-dimension rows a workgroup
                         walks through before its first output row (pipeline
                         fill + halo); 0 = not a streaming kernel */
-  int32_t reserved[3];
+  int32_t origin_align; /* > 1: the kernel starts its dimension-0 tiles at box_lo[0]
+                           rounded down to a multiple of this (cache-line aligned
+                           strips) and tile[0] is exact; 0/1: tiles start at
+                           box_lo[0] (tile[0] already allows for the kernel's own
+                           rounding) */
+  int32_t reserved[2];
 } soda_hip_kernel;
 
 /* By-value argument of every generated kernel. */

@@ -204,8 +204,10 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
   for (int d = 0; d < 3; ++d) out->grid[d] = 1;
   if (dim > 3) return fail(SODA_HIP_ERR_INTERNAL, "4-D launches are not implemented");
   for (int d = 0; d < dim; ++d) {
-    const int64_t extent = args.box_hi[d] - args.box_lo[d];
+    int64_t extent = args.box_hi[d] - args.box_lo[d];
     if (extent <= 0) { *empty = true; return 0; }
+    if (d == 0 && desc.origin_align > 1)   // tiles start at an aligned column
+      extent += args.box_lo[0] % desc.origin_align;
     if (desc.tile[d] <= 0)
       return fail(SODA_HIP_ERR_INTERNAL, "kernel %s has tile[%d]=%d", desc.name, d,
                   desc.tile[d]);

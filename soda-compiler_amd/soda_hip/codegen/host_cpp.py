@@ -219,10 +219,12 @@ def print_code(spec, kernels, out, lowered=None):
   w('  memset(k, 0, sizeof(soda_hip_kernel) * %d);\n' % len(kernels))
   for i, kd in enumerate(kernels):
     w('  snprintf(k[%d].name, sizeof k[%d].name, "%s"); k[%d].kind = %s; '
-      'k[%d].depth = %d; k[%d].stage = %d; k[%d].fill_rows = %d;\n' % (
+      'k[%d].depth = %d; k[%d].stage = %d; k[%d].fill_rows = %d; '
+      'k[%d].origin_align = %d;\n' % (
           i, i, kd['name'], i,
           'SODA_HIP_KERNEL_FUSED' if kd['kind'] == 'fused' else 'SODA_HIP_KERNEL_STAGE',
-          i, kd['depth'], i, kd['stage'], i, kd.get('fill_rows', 0)))
+          i, kd['depth'], i, kd['stage'], i, kd.get('fill_rows', 0),
+          i, kd.get('origin_align', 0)))
     w('  { static const int32_t b[] = %s, t[] = %s; for (int d = 0; d < 3; ++d) '
       'k[%d].block[d] = b[d]; for (int d = 0; d < 4; ++d) k[%d].tile[d] = t[d]; }\n'
       % (_array(kd['block']), _array(kd['tile']), i, i))

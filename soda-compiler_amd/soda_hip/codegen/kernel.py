@@ -37,6 +37,15 @@ AUTO_WP_VGPRS = 200
 AUTO_WP_GROUPS = 4
 AUTO_WP_BUDGET = 200
 WAVE_PIPELINE_MIN_DEPTH = 4
+# Shallow fused kernels are HBM-bound: their strips start and end on 128-byte
+# lines (kernel_stream2d.geometry, align='full'; +7..10 % measured at depth 1-2,
+# nothing at 4, a loss from depth 8 on where the VALU bounds and the extra halo
+# columns cost more than the alignment saves).
+ALIGN_FULL_MAX_DEPTH = 2
+# ... and only programs that are light on arithmetic (denoise2d, ~70 weighted
+# operations per cell, is VALU-bound at depth 1 and loses 19 % to the narrower
+# aligned strips; blur 20, sobel2d 28, jacobi2d 5 gain)
+ALIGN_FULL_MAX_WEIGHT = 40
 
 HIPCC_FLAGS = ['-x', 'hip', '--offload-arch=gfx950', '--cuda-device-only',
                '--no-gpu-bundle-output', '-O3', '-ffp-contract=off',
@@ -90,6 +99,18 @@ def flags_from_text(text):
   return []
 
 
+def arithmetic_weight(spec):
+  """Rough VALU cost of one iteration per cell: operators of all stages,
+  divisions and math calls weighted 8."""
+  weight = 0
+  for stage in spec['stages']:
+    for text in [let['expr'] for let in stage['lets']] + [stage['expr']]:
+      text = re.sub(r'\{[^}]*\}', 'L', kernel_common.device_expr(text))
+      weight += len(re.findall(r'(?<=[\w)\s])[-+*](?=[\s\w(])', text))
+      weight += 8 * (text.count('/') + len(re.findall(r'soda_fn_\w+', text)))
+  return weight
+
+
 def default_cols(spec):
   """Columns per lane: the widest vector (<= 16 bytes) the DSL's burst width
   allows; `burst width: 512` (64 bytes per FPGA burst) gives 16-byte lanes."""
@@ -138,6 +159,10 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
       common = dict(cols=cols if cols else default_cols(spec),
                     chunk_rows=chunk_rows or 256,
                     prefetch=3 if prefetch is None else prefetch)
+      if 'align' not in fused_options:
+        common['align'] = 'full' if (
+            depth <= ALIGN_FULL_MAX_DEPTH and
+            arithmetic_weight(spec) <= ALIGN_FULL_MAX_WEIGHT) else 'none'
       single = piped = None
       if groups <= 1 or depth < WAVE_PIPELINE_MIN_DEPTH or groups == -1:
         try:
@@ -151,7 +176,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
               single is None or single[1]['est_vgprs'] > AUTO_WP_VGPRS)))
       if want_piped:
         options = {k: v for k, v in fused_options.items()
-                   if k in ('skip_fill', 'vgpr_budget', 'max_period', 'pairs')}
+                   if k in ('skip_fill', 'vgpr_budget', 'max_period', 'pairs', 'align')}
         if groups == -1:
           options.setdefault('vgpr_budget', AUTO_WP_BUDGET)
           options.setdefault('pairs', int(kernel_stream2d_wp.packable(spec)))

@@ -103,21 +103,43 @@ def build_pipeline(spec, depth, prefetch):
   return insts, final
 
 
-def geometry(spec, depth, cols, chunk_rows):
-  """Strip/chunk geometry for `depth` fused iterations."""
+def geometry(spec, depth, cols, chunk_rows, align='none'):
+  """Strip/chunk geometry for `depth` fused iterations.
+
+  align: 'none'  - strips as wide as the halo allows;
+         'store' - every strip's OUTPUT columns start and end on a 128-byte line
+                   (no line is written by two wavefronts);
+         'full'  - the loaded columns start on a line as well.
+  Measured with the kernels' access pattern on a 16384x16384 float array
+  (tools/copybench.hip, strips of 256 loaded columns): 248 out / halo 4 508 us,
+  232/12 520 us, 224/16 487 us, 224/0 (both aligned) 445 us, 192/32 431 us,
+  256/0 382 us - alignment is worth more than the extra halo reads for the
+  kernels that HBM bounds."""
   margins = specmod.iteration_margins(spec, depth)
   if len(spec['inputs']) == 1 and len(spec['outputs']) == 1:
     lo, hi = margins[-1]
   else:
     lo, hi = margins[0]
+  elem = specmod.ELEM_SIZE[spec['inputs'][0]['c_type']]
+  line = max(cols, 128 // elem)
+  line -= line % cols
   halo_lo = -(-lo[0] // cols) * cols      # padded up to whole vectors
   halo_hi = -(-hi[0] // cols) * cols
+  if align == 'full':
+    halo_lo = -(-lo[0] // line) * line
   w_out = LANES * cols - halo_lo - halo_hi
+  origin_align = cols
+  if align in ('store', 'full') and w_out >= line:
+    w_out -= w_out % line
+    halo_hi = LANES * cols - halo_lo - w_out
+    origin_align = line
+  elif align not in ('none', 'store', 'full'):
+    raise ValueError('align: %r' % (align,))
   if w_out < cols:
     raise NotFusable('depth %d leaves no output columns in a strip' % depth)
   return dict(x_lo=lo[0], x_hi=hi[0], y_lo=lo[1], y_hi=hi[1],
               halo_lo=halo_lo, halo_hi=halo_hi, w_out=w_out,
-              chunk_rows=chunk_rows)
+              chunk_rows=chunk_rows, origin_align=origin_align)
 
 
 def kernel_name(spec, depth):
@@ -125,7 +147,8 @@ def kernel_name(spec, depth):
 
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
-         vgpr_budget=244, waves_per_eu=0, bpermute=0, skip_fill=1, xcd_remap=0, nontemporal=0):
+         vgpr_budget=244, waves_per_eu=0, bpermute=0, skip_fill=1, xcd_remap=0, nontemporal=0,
+         align='none'):
   """Returns (text, kernel table entry) for one fused depth."""
   types = specmod.tensor_c_types(spec)
   index = tensor_index(spec)
@@ -138,7 +161,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
   if cols is None:
     cols = max(1, 16 // elem)
   insts, final = build_pipeline(spec, depth, prefetch)
-  geo = geometry(spec, depth, cols, chunk_rows)
+  geo = geometry(spec, depth, cols, chunk_rows, align)
   for inst in insts:
     for src, rel, _ in inst.reads:
       if abs(rel[0]) > cols:
@@ -354,7 +377,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
             % (WAVES_PER_BLOCK * LANES, occupancy, name))
   emit_line('  const int lane = lane_id();')
   emit_line('  const int wave = __builtin_amdgcn_workitem_id_x() >> 6;')
-  emit_line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % C)
+  emit_line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % geo['origin_align'])
   if xcd_remap:
     # Workgroups are dealt round-robin over the 8 XCDs (each with its own L2):
     # ids b and b+8 share one.  Re-deal them so that every XCD works on a
@@ -392,7 +415,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
   emit_line('}')
   entry = dict(name=name, kind='fused', depth=depth, stage=-1,
                block=[WAVES_PER_BLOCK * LANES, 1, 1],
-               tile=[WAVES_PER_BLOCK * geo['w_out'] - C, chunk_rows, 1, 1],
+               tile=[WAVES_PER_BLOCK * geo['w_out'], chunk_rows, 1, 1],
+               origin_align=geo['origin_align'],
                fill_rows=L + geo['y_lo'],
                cols=C, prefetch=prefetch, period=period, est_vgprs=est_vgprs,
                halo=[geo['halo_lo'], geo['halo_hi']], w_out=geo['w_out'])

@@ -143,7 +143,7 @@ def packable(spec):
 
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
-         max_period=12, vgpr_budget=120, skip_fill=1, pairs=0):
+         max_period=12, vgpr_budget=120, skip_fill=1, pairs=0, align='none'):
   """Returns (text, kernel table entry).
 
   pairs=1 (float programs, see packable()): a wavefront streams TWO adjacent
@@ -166,7 +166,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
     raise NotFusable('packed form: whole 16-byte vectors per lane')
   P = 2 if pairs else 1
   everything, per_wave, final = build_groups(spec, depth, prefetch, groups)
-  geo = geometry(spec, depth, C, chunk_rows)
+  geo = geometry(spec, depth, C, chunk_rows, align)
   for inst in everything:
     for src, rel, _ in inst.reads:
       if abs(rel[0]) > C:
@@ -406,7 +406,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   line('  const int lane = lane_id();')
   line('  const int wave = __builtin_amdgcn_readfirstlane('
        '__builtin_amdgcn_workitem_id_x() >> 6);')
-  line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % C)
+  line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % geo['origin_align'])
   line('  const i64 xs = x_origin + (i64)__builtin_amdgcn_workgroup_id_x() * %d;'
        % (P * geo['w_out']))
   line('  if (xs >= a.box_hi[0]) return;')
@@ -421,7 +421,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   line('}')
   entry = dict(name=name, kind='fused', depth=depth, stage=-1,
                block=[groups * LANES, 1, 1],
-               tile=[P * geo['w_out'] - C, chunk_rows, 1, 1], pairs=int(bool(pairs)),
+               tile=[P * geo['w_out'], chunk_rows, 1, 1], pairs=int(bool(pairs)),
+               origin_align=geo['origin_align'],
                fill_rows=L + geo['y_lo'], cols=C, prefetch=prefetch, period=period,
                est_vgprs=est_vgprs, groups=groups, w_out=geo['w_out'])
   return '\n'.join(o) + '\n', entry

@@ -41,7 +41,8 @@ class KernelDesc(ctypes.Structure):
   _fields_ = [('name', ctypes.c_char * 96), ('kind', ctypes.c_int32),
               ('depth', ctypes.c_int32), ('stage', ctypes.c_int32),
               ('block', ctypes.c_int32 * 3), ('tile', ctypes.c_int32 * MAX_DIMS),
-              ('fill_rows', ctypes.c_int32), ('reserved', ctypes.c_int32 * 3)]
+              ('fill_rows', ctypes.c_int32), ('origin_align', ctypes.c_int32),
+              ('reserved', ctypes.c_int32 * 2)]
 
 
 class Timing(ctypes.Structure):

@@ -181,6 +181,7 @@ def kernel_descs(table):
     for i in range(4):
       d.tile[i] = k['tile'][i]
     d.fill_rows = k.get('fill_rows', 0)
+    d.origin_align = k.get('origin_align', 0)
   return arr
 
 

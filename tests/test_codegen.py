@@ -118,7 +118,7 @@ def test_wave_pipelined_forms_compile(options, tmp_path):
   assert fused and fused[0]['groups'] == 4 and fused[0]['block'] == [256, 1, 1]
   assert fused[0]['pairs'] == options.get('pairs', 0)
   if options.get('pairs'):
-    assert fused[0]['tile'][0] == 2 * fused[0]['w_out'] - fused[0]['cols']
+    assert fused[0]['tile'][0] == 2 * fused[0]['w_out']
     assert 'pk2' in text
   out = tmp_path / 'wp.hsaco'
   kernel.compile_to_code_object(text, str(out))

@@ -11,7 +11,7 @@ from soda_hip.codegen import kernel, spec as specmod
 from soda_hip.runtime import host
 from oracle import soda_oracle
 app = sys.argv[1]
-opts = {k: int(v) for k, v in (kv.split('=') for kv in sys.argv[2].split(','))} if len(sys.argv) > 2 and sys.argv[2] else {}
+opts = {k: (int(v) if v.lstrip('-').isdigit() else v) for k, v in (kv.split('=') for kv in sys.argv[2].split(','))} if len(sys.argv) > 2 and sys.argv[2] else {}
 ok = True
 for iterate, shape in ((12, (300, 1100)), (25, (257, 1021)), (13, (100, 2049)), (37, (611, 700)), (8, (64, 64))):
   st = frontend.load(os.path.join(ROOT, 'tests', 'samples', app + '.soda'), iterate=iterate)

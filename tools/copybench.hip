@@ -40,6 +40,30 @@ __global__ void __launch_bounds__(256) copy_rows(const float* __restrict__ in, f
   }
 }
 
+// the fused kernels' geometry: overlapped strips, each wave loads 256 floats from
+// xs - halo_lo and stores the w_out floats that start at xs; WPB waves per block
+template <int PF, int WPB>
+__global__ void __launch_bounds__(64 * WPB) copy_strips(const float* __restrict__ in, float* __restrict__ out, long W, long H, long chunk, int w_out, int halo_lo) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long xs = ((long)blockIdx.x * WPB + wave) * w_out + halo_lo;
+  if (xs >= W - 256) return;
+  const long x = xs - halo_lo + lane * 4;
+  const bool st = x >= xs && x + 4 <= xs + w_out;
+  const long y0 = (long)blockIdx.y * chunk, y1 = y0 + chunk < H ? y0 + chunk : H;
+  float4v ring[PF];
+#pragma unroll
+  for (int p = 0; p < PF; ++p) { long y = y0 + p < H ? y0 + p : H - 1; ring[p] = *(const float4v*)(in + y * W + x); }
+  for (long y = y0; y < y1; y += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      float4v v = ring[p];
+      long yn = y + p + PF; if (yn > H - 1) yn = H - 1;
+      ring[p] = *(const float4v*)(in + yn * W + x);
+      if (st && y + p < y1) *(float4v*)(out + (y + p) * W + x) = v;
+    }
+  }
+}
+
 template <typename F> void timeit(const char* name, size_t bytes, F f) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   f(); CK(hipDeviceSynchronize());
@@ -66,6 +90,19 @@ int main() {
     snprintf(nm, sizeof nm, "rows plain pf6 chunk=%ld", chunk); timeit(nm, bytes, [&] { copy_rows<0,0,6><<<grid,256>>>(a, b, W, H, chunk); });
     snprintf(nm, sizeof nm, "rows nt-ld nt-st pf6 chunk=%ld", chunk); timeit(nm, bytes, [&] { copy_rows<1,1,6><<<grid,256>>>(a, b, W, H, chunk); });
     snprintf(nm, sizeof nm, "rows nt-st pf6 chunk=%ld", chunk); timeit(nm, bytes, [&] { copy_rows<0,1,6><<<grid,256>>>(a, b, W, H, chunk); });
+  }
+  struct G { int w_out, halo_lo; };
+  for (G g : {G{256, 0}, G{248, 4}, G{232, 12}, G{224, 16}, G{224, 0}, G{192, 32}}) {
+    for (long chunk : {256L, 576L}) {
+      const long strips = (W - 256) / g.w_out;
+      char nm[128];
+      dim3 g1((unsigned)strips, (unsigned)((H + chunk - 1) / chunk));
+      snprintf(nm, sizeof nm, "strips w_out=%d halo_lo=%d chunk=%ld 1 wave/blk", g.w_out, g.halo_lo, chunk);
+      timeit(nm, (size_t)strips * g.w_out * H * 4, [&] { copy_strips<3, 1><<<g1, 64>>>(a, b, W, H, chunk, g.w_out, g.halo_lo); });
+      dim3 g4((unsigned)((strips + 3) / 4), (unsigned)((H + chunk - 1) / chunk));
+      snprintf(nm, sizeof nm, "strips w_out=%d halo_lo=%d chunk=%ld 4 waves/blk", g.w_out, g.halo_lo, chunk);
+      timeit(nm, (size_t)strips * g.w_out * H * 4, [&] { copy_strips<3, 4><<<g4, 256>>>(a, b, W, H, chunk, g.w_out, g.halo_lo); });
+    }
   }
   return 0;
 }

@@ -16,14 +16,15 @@ st = frontend.load(os.path.join(ROOT, 'tests', 'samples', app + '.soda'), iterat
 spec = specmod.spec_from_stencil(st)
 dims = [w, h]
 rng = np.random.default_rng(1)
-a = rng.random((h, w), dtype=np.float32)
+dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
+a = rng.random((h, w), dtype=np.float32).astype(dt) if dt.kind == 'f' else rng.integers(0, 65536, size=(h, w)).astype(dt)
 din = host.DeviceArray(a.nbytes); din.upload(a)
 dout = host.DeviceArray(a.nbytes); dout.zero()
 for variant in sys.argv[4:]:
   parts = variant.split(',')
   depth, cols, chunk, pf = [int(v) for v in parts[:4]]
   extra = dict(kv.split('=') for kv in parts[4:])
-  extra = {k: int(v) for k, v in extra.items()}
+  extra = {k: (int(v) if v.lstrip('-').isdigit() else v) for k, v in extra.items()}
   t0 = time.time()
   if 'wave_groups' not in extra:
     extra.setdefault('vgpr_budget', 400)
