@@ -152,7 +152,11 @@ typedef struct soda_hip_kernel {
                            strips) and tile[0] is exact; 0/1: tiles start at
                            box_lo[0] (tile[0] already allows for the kernel's own
                            rounding) */
-  int32_t reserved[2];
+  int32_t min_extent[2]; /* > 0: the kernel handles only arrays with dims[0] and
+                            dims[1] at least this large (its tiles are moved
+                            inside the array rather than guarded) and fewer than
+                            2^30 cells per plane (32-bit in-plane offsets); the
+                            scheduler skips it otherwise */
 } soda_hip_kernel;
 
 /* By-value argument of every generated kernel. */

@@ -290,10 +290,18 @@ int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
   // fused kernels available?  (single hull box => single-output programs, or
   // outputs that share a window; the printer only emits them when that holds)
   std::vector<int> fused;  // kernel indices sorted by depth descending
-  for (size_t k = 0; k < plan->kernels.size(); ++k)
-    if (plan->kernels[k].kind == SODA_HIP_KERNEL_FUSED &&
-        (plan->max_depth <= 0 || plan->kernels[k].depth <= plan->max_depth))
-      fused.push_back((int)k);
+  for (size_t k = 0; k < plan->kernels.size(); ++k) {
+    const soda_hip_kernel& kd = plan->kernels[k];
+    if (kd.kind != SODA_HIP_KERNEL_FUSED ||
+        (plan->max_depth > 0 && kd.depth > plan->max_depth))
+      continue;
+    // kernels without a guarded path: only arrays at least one tile large
+    if (kd.min_extent[0] > 0 &&
+        (dims[0] < kd.min_extent[0] || (p.dim > 1 && dims[1] < kd.min_extent[1]) ||
+         (p.dim > 1 && dims[0] * dims[1] >= (int64_t(1) << 30))))
+      continue;
+    fused.push_back((int)k);
+  }
   std::sort(fused.begin(), fused.end(), [&](int a, int b) {
     return plan->kernels[a].depth > plan->kernels[b].depth;
   });
@@ -677,8 +685,17 @@ int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* progra
       const int threads = pl->kernels[k].block[0] * pl->kernels[k].block[1] *
                           pl->kernels[k].block[2];
       const int waves_per_block = std::max(1, (threads + 63) / 64);
-      pl->resident_blocks.push_back(
-          std::max(1, cus * (4 * waves_per_simd / waves_per_block)));
+      int per_cu = 4 * waves_per_simd / waves_per_block;
+      // the runtime's own answer also knows the kernel's LDS and SGPR use
+      int api = 0;
+      if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(
+              &api, pl->funcs[k], threads, 0) == hipSuccess && api > 0)
+        per_cu = api;
+      if (getenv("SODA_HIP_DEBUG"))
+        fprintf(stderr, "soda_hip: kernel %s: %d VGPRs, %d workgroup(s) of %d "
+                "wavefronts per CU\n", pl->kernels[k].name, regs, per_cu,
+                waves_per_block);
+      pl->resident_blocks.push_back(std::max(1, cus * per_cu));
     }
     const soda_hip_kernel& d = pl->kernels[k];
     if (d.block[0] < 1 || d.block[1] < 1 || d.block[2] < 1 ||

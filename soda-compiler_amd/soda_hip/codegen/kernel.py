@@ -20,7 +20,7 @@ import tempfile
 
 from .. import __version__
 from . import (kernel_common, kernel_stage, kernel_stream2d, kernel_stream2d_wp,
-               kernel_stream3d)
+               kernel_stream3d, kernel_stream3d_wp)
 from . import spec as specmod
 
 DEFAULT_MAX_DEPTH = 12
@@ -42,6 +42,12 @@ WAVE_PIPELINE_MIN_DEPTH = 4
 # nothing at 4, a loss from depth 8 on where the VALU bounds and the extra halo
 # columns cost more than the alignment saves).
 ALIGN_FULL_MAX_DEPTH = 2
+# 3-D: depths beyond the single-wave form, built wave-pipelined (kernel_stream3d_wp)
+DEEP_3D_DEPTHS = (4,)
+# ... for programs light enough that memory, not the VALU, bounds them: jacobi3d
+# (weight 7) 417 us per depth-4 launch against 2 x 374 us at depth 2; heat3d
+# (weight 15) 810 us against 2 x 406 us - no gain, so it keeps depth 2
+DEEP_3D_MAX_WEIGHT = 10
 # ... and only programs that are light on arithmetic (denoise2d, ~70 weighted
 # operations per cell, is VALU-bound at depth 1 and loses 19 % to the narrower
 # aligned strips; blur 20, sobel2d 28, jacobi2d 5 gain)
@@ -206,7 +212,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
     for depth in wanted3:
       # rows per lane: as many as the register file allows (taller tiles waste
       # less on the y halo)
-      options = dict(fused_options)
+      options = {k: v for k, v in fused_options.items() if not k.startswith('wp_')}
       row_choices = [options.pop("rows")] if "rows" in options else [16, 12]
       error = None
       for rows in row_choices:
@@ -221,6 +227,24 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
         break
       if error is not None:
         notes.append('depth %d not fused: %s' % (depth, error))
+    # deeper than one wavefront's registers allow: one level per wavefront
+    deep = [d for d in (depths if depths is not None else DEEP_3D_DEPTHS)
+            if d > 2 and d <= max(1, spec['iterate'])]
+    if len(spec['inputs']) == len(spec['outputs']) == 1 and (
+        depths is not None or arithmetic_weight(spec) <= DEEP_3D_MAX_WEIGHT):
+      for depth in deep:
+        options = {k[3:]: v for k, v in fused_options.items()
+                   if k in ('wp_rows', 'wp_groups', 'wp_prefetch', 'wp_vgpr_budget', 'wp_split',
+                           'wp_lds_budget', 'wp_waves_per_eu', 'wp_loader',
+                           'wp_ring_prefetch')}
+        options.setdefault('groups', min(depth * len(spec['stages']), 4))
+        try:
+          ftext, entry = kernel_stream3d_wp.emit(spec, depth, **options)
+        except kernel_stream2d.NotFusable as e:
+          notes.append('depth %d not wave-pipelined: %s' % (depth, e))
+          continue
+        parts.append(ftext)
+        table.append(entry)
   if notes:
     parts.append(''.join('// %s\n' % n for n in notes))
   parts.append(kernel_common.meta_symbol(

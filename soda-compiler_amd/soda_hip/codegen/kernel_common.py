@@ -178,6 +178,19 @@ template <typename T, bool BELOW> DEV T lane_neighbour_bp(T v) {
   return __builtin_bit_cast(T, __builtin_amdgcn_ds_bpermute(
       src, __builtin_bit_cast(int, v)));
 }
+// Rows across the two 32-lane halves of a wavefront (v_permlane32_swap): `first`
+// and `last` are a lane's first and last tile rows.  The upper half receives in
+// `above` the lower half's `last` (the row above its first one), the lower half
+// receives in `below` the upper half's `first`; the other halves get their own
+// values back (tile-edge halo, never used for a stored cell).
+template <typename T> DEV void rows_across_halves(T first, T last, T& above, T& below) {
+  static_assert(sizeof(T) == 4, "rows_across_halves: 4-byte elements");
+  const auto r = __builtin_amdgcn_permlane32_swap(
+      __builtin_bit_cast(unsigned, first), __builtin_bit_cast(unsigned, last),
+      false, false);
+  above = __builtin_bit_cast(T, (unsigned)r[0]);
+  below = __builtin_bit_cast(T, (unsigned)r[1]);
+}
 template <typename T> DEV T from_lane_below_bp(T v) { return lane_neighbour_bp<T, true>(v); }
 template <typename T> DEV T from_lane_above_bp(T v) { return lane_neighbour_bp<T, false>(v); }
 template <typename T> DEV T from_lane_below(T v) { return lane_neighbour<T, true>(v); }

@@ -37,9 +37,14 @@ from .kernel_common import builtin_type, device_expr, tensor_index
 from .kernel_stream2d import LANES, Instance, NotFusable, geometry, kernel_name
 
 
-def build_groups(spec, depth, prefetch, groups):
-  if spec['dim'] != 2:
-    raise NotFusable('2-D programs only')
+def build_groups(spec, depth, prefetch, groups, loader=False):
+  """Stage instances of `depth` iterations cut into `groups` wavefronts; the
+  streamed dimension is the last one (rows in 2-D, planes in 3-D).
+
+  loader=True: the program input does not come through the registers of group
+  0 but through an LDS ring that a separate loader wavefront fills (role
+  'ring_in' of the copy that group 0 reads, one step behind the ring)."""
+  axis = spec['dim'] - 1
   if len(spec['outputs']) != 1 or len(spec['inputs']) != 1:
     raise NotFusable('one input, one output')
   types = specmod.tensor_c_types(spec)
@@ -81,6 +86,10 @@ def build_groups(spec, depth, prefetch, groups):
     src.handoff = g - 1
     copy.handoff = g - 1
     copies[id(src)] = copy
+  ring = None
+  if loader:
+    ring = Instance('r_%s' % source.ident, source.tensor, 0, source.c_type)
+    ring.role, ring.group, ring.origin = 'ring_in', 0, source
   for inst in stages:
     reads = []
     for src, rel, name in inst.reads:
@@ -88,6 +97,8 @@ def build_groups(spec, depth, prefetch, groups):
         if inst.group != 0:
           raise NotFusable('%s reads the program input from group %d'
                            % (inst.ident, inst.group))
+        if loader:
+          src = ring
       elif src.group != inst.group:
         if src is not last_of[inst.group - 1] or src.group != inst.group - 1:
           raise NotFusable('%s reads %s across wavefront groups'
@@ -98,25 +109,23 @@ def build_groups(spec, depth, prefetch, groups):
   # lags, in execution order; a hand-off arrives one step after it was produced
   source.lag = 0
   for inst in stages:
-    if id(inst) in copies and False:
-      pass
     lag = None
     for src, rel, _ in inst.reads:
-      if src.role == 'lds_in':
+      if src.role in ('lds_in', 'ring_in'):
         src.lag = src.origin.lag + 1
-      v = src.lag + rel[1] + (prefetch if src is source else 0)
+      v = src.lag + rel[axis] + (prefetch if src is source else 0)
       lag = v if lag is None else max(lag, v)
     inst.lag = lag
-  everything = [source] + stages + list(copies.values())
+  everything = [source] + stages + list(copies.values()) + ([ring] if loader else [])
   for inst in stages:
     for src, rel, _ in inst.reads:
-      src.keep = max(src.keep, inst.lag - rel[1] - src.lag + 1)
+      src.keep = max(src.keep, inst.lag - rel[axis] - src.lag + 1)
   for inst in stages:
     if inst.role == 'compute' and not inst.final and inst.keep == 0:
       raise NotFusable('stage %s is never read' % inst.tensor)
   per_wave = []
   for g in range(groups):
-    mine = [source] if g == 0 else [copies[id(last_of[g - 1])]]
+    mine = [ring if loader else source] if g == 0 else [copies[id(last_of[g - 1])]]
     mine += stages[bounds[g]:bounds[g + 1]]
     per_wave.append(mine)
   return everything, per_wave, final
@@ -165,6 +174,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   if pairs and (C * elem) % 16:
     raise NotFusable('packed form: whole 16-byte vectors per lane')
   P = 2 if pairs else 1
+  if spec['dim'] != 2:
+    raise NotFusable('2-D programs only')
   everything, per_wave, final = build_groups(spec, depth, prefetch, groups)
   geo = geometry(spec, depth, C, chunk_rows, align)
   for inst in everything:

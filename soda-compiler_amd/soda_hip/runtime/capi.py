@@ -42,7 +42,7 @@ class KernelDesc(ctypes.Structure):
               ('depth', ctypes.c_int32), ('stage', ctypes.c_int32),
               ('block', ctypes.c_int32 * 3), ('tile', ctypes.c_int32 * MAX_DIMS),
               ('fill_rows', ctypes.c_int32), ('origin_align', ctypes.c_int32),
-              ('reserved', ctypes.c_int32 * 2)]
+              ('min_extent', ctypes.c_int32 * 2)]
 
 
 class Timing(ctypes.Structure):

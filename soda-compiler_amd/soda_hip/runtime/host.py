@@ -182,6 +182,8 @@ def kernel_descs(table):
       d.tile[i] = k['tile'][i]
     d.fill_rows = k.get('fill_rows', 0)
     d.origin_align = k.get('origin_align', 0)
+    for i, v in enumerate(k.get('min_extent', [0, 0])):
+      d.min_extent[i] = v
   return arr
 
 

@@ -131,6 +131,27 @@ def test_wave_pipelined_forms_compile(options, tmp_path):
                             pairs=1)
 
 
+def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
+  """Depth-4 3-D kernel: one level per wavefront, 64x32 tiles, declares the
+  smallest array it accepts; programs it does not cover keep depth <= 2."""
+  spec = spec_of('jacobi3d', iterate=8)
+  text, table = kernel.generate(spec)
+  k4 = [k for k in table if k['kind'] == 'fused' and k['depth'] == 4]
+  assert k4 and k4[0]['groups'] == 4 and k4[0]['block'] == [256, 1, 1]
+  assert k4[0]['min_extent'] == [64, 32] and k4[0]['tile'][:2] == [56, 24]
+  assert k4[0]['lds_bytes'] <= 64 * 1024
+  assert 'v_permlane32_swap' in text or 'rows_across_halves' in text
+  out = tmp_path / 'j3d.hsaco'
+  kernel.compile_to_code_object(text, str(out))
+  assert open(out, 'rb').read(4) == b'\x7fELF'
+  # two inputs: no iteration chain, no deep kernel
+  table = kernel.generate(spec_of('denoise3d'))[1]
+  assert max(k['depth'] for k in table) <= 1
+  # iterate below the depth: not generated
+  table = kernel.generate(spec_of('jacobi3d', iterate=3))[1]
+  assert max(k['depth'] for k in table) == 2
+
+
 def test_pipeline_lags_match_the_reference_reuse_model():
   """jacobi2d: each level trails the previous by one row and keeps three rows
   (the reference's reuse chain for a 3-row window is 2 rows + 1)."""

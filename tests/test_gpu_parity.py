@@ -161,6 +161,59 @@ def test_3d_fused_plane_streaming(app, shape, iterate, max_depth):
   check(app, gpu_util.random_inputs(spec, shape), iterate, max_depth)
 
 
+@pytest.mark.parametrize('app', ['jacobi3d'])
+@pytest.mark.parametrize('shape,iterate', [
+    ((20, 32, 64), 4), ((30, 33, 65), 4), ((24, 35, 67), 8), ((40, 100, 200), 9),
+    ((44, 61, 130), 13), ((12, 90, 64), 5), ((300, 40, 70), 4)])
+def test_3d_wave_pipelined_depth_4(app, shape, iterate):
+  """The depth-4 wave-pipelined 3-D kernel (one level per wavefront, plane tiles
+  through LDS, 64x32 tiles made of two row blocks joined by v_permlane32_swap,
+  overhanging tiles moved inside the array): exactly one tile, one cell more than
+  a tile, ragged edges in x and y, z-chunks with remainders."""
+  prog = program(app)
+  names = [k['name'] for k in prog.kernels]
+  assert app + '_fused_k4' in names, names
+  spec = gpu_util.load_spec(app)
+  inputs = gpu_util.random_inputs(spec, shape)
+  check(app, inputs, iterate)
+  timing = prog.run_numpy(inputs, iterate=iterate, timed=True)[1]
+  assert timing['max_depth'] == 4, timing
+
+
+@pytest.mark.parametrize('options', [dict(), dict(wp_loader=1, wp_waves_per_eu=3),
+                                     dict(wp_split=1), dict(wp_prefetch=1)])
+def test_3d_wave_pipelined_forms_on_heat3d(options):
+  """The depth-4 generator on a program it is not the default for (heat3d, FMA-
+  sensitive expression), and its optional forms: LDS-direct loader wavefront,
+  one row block per wavefront, register prefetch."""
+  from soda_hip.codegen import kernel
+  for shape, iterate in (((30, 45, 70), 4), ((24, 64, 131), 9)):
+    spec = gpu_util.load_spec('heat3d', iterate=iterate)
+    text, table = kernel.generate(spec, depths=[2, 4], **options)
+    assert any(k['depth'] == 4 for k in table)
+    prog = host.open_program(source=text, spec=spec)
+    inputs = gpu_util.random_inputs(spec, shape)
+    got, timing = prog.run_numpy(inputs, iterate=iterate, timed=True)
+    assert timing['max_depth'] == 4
+    orc = soda_oracle.Oracle(spec)
+    want = orc.run(inputs, iterate=iterate)[spec['outputs'][0]]
+    sl = orc.valid_slices(tuple(reversed(shape)), iterate)
+    assert np.array_equal(got[0][sl], want[sl], equal_nan=True), (options, shape)
+    prog.close()
+    prog.blob.unload()
+
+
+def test_small_arrays_skip_kernels_without_a_guarded_path():
+  """Arrays smaller than one 64x32 tile are served by the shallower fused
+  kernels (soda_hip_kernel.min_extent), with the same results."""
+  spec = gpu_util.load_spec('jacobi3d')
+  prog = program('jacobi3d')
+  for shape in ((40, 31, 100), (40, 50, 63), (16, 20, 20)):
+    inputs = gpu_util.random_inputs(spec, shape)
+    check('jacobi3d', inputs, 4)
+    assert prog.run_numpy(inputs, iterate=4, timed=True)[1]['max_depth'] == 2
+
+
 def test_empty_valid_region_is_not_an_error():
   """iterate so large that nothing is left: nothing launched, zeros back."""
   spec = gpu_util.load_spec('jacobi2d')

@@ -11,11 +11,13 @@ from soda_hip.codegen import kernel, spec as specmod
 from soda_hip.runtime import host
 
 app, iterate = sys.argv[1], int(sys.argv[3])
-w, h = ([int(v) for v in sys.argv[2].split('x')] * 2)[:2]
+size = [int(v) for v in sys.argv[2].split('x')]
 st = frontend.load(os.path.join(ROOT, 'tests', 'samples', app + '.soda'), iterate=iterate)
 spec = specmod.spec_from_stencil(st)
-dims = [w, h]
+dims = (size * spec['dim'])[:spec['dim']] if len(size) == 1 else size
+w, h = dims[0], int(np.prod(dims[1:]))
 rng = np.random.default_rng(1)
+dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
 dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
 a = rng.random((h, w), dtype=np.float32).astype(dt) if dt.kind == 'f' else rng.integers(0, 65536, size=(h, w)).astype(dt)
 din = host.DeviceArray(a.nbytes); din.upload(a)
@@ -38,5 +40,5 @@ for variant in sys.argv[4:]:
   valid = specmod.valid_cells(spec, dims, iterate)
   print('%-28s compile %.1fs  %8.1f us/sweep  %d launches  dominant %s %.1f us  -> %.0f Gcell/s valid (%.0f nominal)' % (
       variant, tc, t['kernel_us'], t['launches'], t['dominant_name'], t['dominant_us'] / t['dominant_launches'],
-      valid / t['kernel_us'] / 1e3, w * h * iterate / t['kernel_us'] / 1e3), flush=True)
+      valid / t['kernel_us'] / 1e3, float(w) * h * iterate / t['kernel_us'] / 1e3), flush=True)
   prog.close(); prog.blob.unload()
