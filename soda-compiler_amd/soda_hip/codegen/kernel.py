@@ -44,10 +44,10 @@ WAVE_PIPELINE_MIN_DEPTH = 4
 ALIGN_FULL_MAX_DEPTH = 2
 # 3-D: depths beyond the single-wave form, built wave-pipelined (kernel_stream3d_wp)
 DEEP_3D_DEPTHS = (4,)
-# ... for programs light enough that memory, not the VALU, bounds them: jacobi3d
-# (weight 7) 417 us per depth-4 launch against 2 x 374 us at depth 2; heat3d
-# (weight 15) 810 us against 2 x 406 us - no gain, so it keeps depth 2
-DEEP_3D_MAX_WEIGHT = 10
+# ... for programs light enough on arithmetic: jacobi3d (weight 7) 417 us per
+# depth-4 launch against 2 x 374 us at depth 2, heat3d (15) 622 us against
+# 2 x 411 us; heavier programs are VALU-bound at depth 2 already
+DEEP_3D_MAX_WEIGHT = 20
 # ... and only programs that are light on arithmetic (denoise2d, ~70 weighted
 # operations per cell, is VALU-bound at depth 1 and loses 19 % to the narrower
 # aligned strips; blur 20, sobel2d 28, jacobi2d 5 gain)

@@ -28,7 +28,7 @@ from .kernel_stream3d import kernel_name
 
 def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
          max_period=12, vgpr_budget=200, lds_budget=64 * 1024, split=2,
-         waves_per_eu=0, loader=0, ring_prefetch=2):
+         waves_per_eu=2, loader=0, ring_prefetch=2):
   """Returns (text, kernel table entry).
 
   split=2: the wavefront is a 32 x 2 grid of lanes; lane (lx, ly) holds columns
@@ -38,6 +38,14 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   against 120x8 of 128x16 (47 %) - less redundant arithmetic and fewer halo
   cells fetched.  Rows that cross the halves come from one v_permlane32_swap per
   register (tools/permlane_test.hip).
+
+  waves_per_eu=2: the register allocator may not go beyond 256 VGPRs.  Left
+  alone the scheduler hoists the next planes' loads above the current plane's
+  arithmetic in the loading wavefront (its own prefetch, 32 registers per plane);
+  heat3d then needs 274 VGPRs, one workgroup per CU, 814 us per launch - capped,
+  622 us with 24 spilled registers.  (`-amdgpu-sched-strategy=iterative-ilp`
+  finds a 216-register schedule, 506 us, but it is a per-translation-unit,
+  experimental switch.)
 
   loader=1 (with split=2, EXPERIMENTAL, off): an extra wavefront does nothing but
   stream input plane tiles into an LDS ring with LDS-direct loads

@@ -161,7 +161,7 @@ def test_3d_fused_plane_streaming(app, shape, iterate, max_depth):
   check(app, gpu_util.random_inputs(spec, shape), iterate, max_depth)
 
 
-@pytest.mark.parametrize('app', ['jacobi3d'])
+@pytest.mark.parametrize('app', ['jacobi3d', 'heat3d'])
 @pytest.mark.parametrize('shape,iterate', [
     ((20, 32, 64), 4), ((30, 33, 65), 4), ((24, 35, 67), 8), ((40, 100, 200), 9),
     ((44, 61, 130), 13), ((12, 90, 64), 5), ((300, 40, 70), 4)])
@@ -183,8 +183,8 @@ def test_3d_wave_pipelined_depth_4(app, shape, iterate):
 @pytest.mark.parametrize('options', [dict(), dict(wp_loader=1, wp_waves_per_eu=3),
                                      dict(wp_split=1), dict(wp_prefetch=1)])
 def test_3d_wave_pipelined_forms_on_heat3d(options):
-  """The depth-4 generator on a program it is not the default for (heat3d, FMA-
-  sensitive expression), and its optional forms: LDS-direct loader wavefront,
+  """The depth-4 generator on heat3d (FMA-sensitive expression) in its optional
+  forms: LDS-direct loader wavefront,
   one row block per wavefront, register prefetch."""
   from soda_hip.codegen import kernel
   for shape, iterate in (((30, 45, 70), 4), ((24, 64, 131), 9)):
