@@ -301,7 +301,8 @@ class Program:
     outs = []
     for name, a in zip(spec['outputs'], raw):
       lo, hi = boxes[name]
-      sl = tuple(slice(-lo[d], dims[d] - hi[d])
+      # (an empty box stays empty: a negative stop would wrap around in numpy)
+      sl = tuple(slice(-lo[d], max(-lo[d], dims[d] - hi[d]))
                  for d in reversed(range(spec['dim'])))
       clean = np.zeros_like(a)
       clean[sl] = a[sl]

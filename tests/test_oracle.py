@@ -106,3 +106,14 @@ def test_independent_numpy_blur():
   bx = ((w[:-2, :] + w[1:-1, :] + w[2:, :]) // 3).astype(np.uint16).astype(np.int32)
   by = ((bx[:, :-2] + bx[:, 1:-1] + bx[:, 2:]) // 3).astype(np.uint16)
   assert np.array_equal(got[:-2, :-2], by)
+
+
+def test_valid_slices_of_an_empty_region_are_empty():
+  """A grid smaller than the composed window has no defined cell; the slices
+  must not wrap around (numpy reads a negative stop from the end)."""
+  spec = specmod.spec_from_stencil(frontend.load(os.path.join(SAMPLES, 'jacobi2d.soda')))
+  orc = soda_oracle.Oracle(spec)
+  sl = orc.valid_slices((30, 12), iterate=8)     # 12 rows, 16 needed
+  assert np.zeros((12, 30))[sl].size == 0
+  sl = orc.valid_slices((30, 18), iterate=8)
+  assert np.zeros((18, 30))[sl].shape == (2, 14)
