@@ -409,23 +409,30 @@ def test_multi_output_host_buffer_protocol():
   prog.close()
 
 
-@pytest.mark.parametrize('world,exchange,iterate', [(2, 12, 30), (3, 5, 17), (4, 24, 48)])
-def test_slab_decomposition_with_the_hip_engine(world, exchange, iterate):
+@pytest.mark.parametrize('app,dims,world,exchange,iterate', [
+    ('jacobi2d', (1500, 611), 2, 12, 30), ('jacobi2d', (1500, 611), 3, 5, 17),
+    ('jacobi2d', (1500, 611), 4, 24, 48),
+    ('jacobi3d', (130, 70, 96), 2, 8, 20), ('jacobi3d', (67, 45, 120), 3, 4, 13),
+    ('heat3d', (100, 64, 90), 2, 12, 24)])
+def test_slab_decomposition_with_the_hip_engine(app, dims, world, exchange, iterate):
   """The multi-GPU driver's slab logic (soda_hip.runtime.dist) run with the REAL
   kernels: all ranks emulated on this one GPU, ghost rows copied by hand where
   RCCL would move them.  Covers what the gloo tests cannot: soda_hip_sweep's
-  valid_lo/valid_hi contract on slabs with ghost rows."""
+  valid_lo/valid_hi contract on slabs with ghost rows (2-D) and ghost planes
+  (3-D, where the depth-4 kernel moves its edge tiles inside the slab)."""
   import torch
   from soda_hip.codegen import spec as specmod
   from soda_hip.runtime import dist as sdist
-  prog = program('jacobi2d')
+  prog = program(app)
   spec = prog.spec
-  w, h = 1500, 611
-  full = np.random.default_rng(11).random((h, w), dtype=np.float32)
+  dim = spec['dim']
+  shape = tuple(reversed(dims))
+  full = np.random.default_rng(11).random(shape, dtype=np.float32)
   table = specmod.iteration_margins(spec, iterate)
-  margins_of = lambda k: ((0, 0), (0, 0)) if k == 0 else table[k - 1]
+  zero = (tuple([0] * dim), tuple([0] * dim))
+  margins_of = lambda k: zero if k == 0 else table[k - 1]
   engine = sdist.HipEngine(prog, torch)
-  plans = [sdist.SlabPlan([w, h], r, world, 1, 1, exchange) for r in range(world)]
+  plans = [sdist.SlabPlan(list(dims), r, world, 1, 1, exchange) for r in range(world)]
   dev = torch.device('cuda', 0)
   cur, nxt = [], []
   for p in plans:
@@ -453,8 +460,9 @@ def test_slab_decomposition_with_the_hip_engine(world, exchange, iterate):
   got = np.zeros_like(full)
   for r, p in enumerate(plans):
     got[p.start:p.stop] = cur[r][p.ghost_lo:p.ghost_lo + p.own].cpu().numpy()
-  want = oracle('jacobi2d').run([full], iterate=iterate)['t0']
-  sl = oracle('jacobi2d').valid_slices((w, h), iterate)
+  want = oracle(app).run([full], iterate=iterate)[spec['outputs'][0]]
+  sl = oracle(app).valid_slices(dims, iterate)
+  assert want[sl].size > 0
   assert np.array_equal(got[sl], want[sl])
 
 
