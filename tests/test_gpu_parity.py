@@ -296,6 +296,49 @@ def test_full_size_properties_jacobi2d_8192():
   assert rel.max() < 1e-4
 
 
+def test_full_size_cfg4_jacobi2d_16384_x1000():
+  """BASELINE config 4, the headline workload, at full size: two windows of the
+  result (one in the middle, one in the corner of the valid region) are compared
+  bit for bit with the oracle run on the sub-grid that holds their whole
+  1000-iteration dependency cone; and the depth-12 schedule agrees with the
+  depth-8 one everywhere."""
+  prog = program('jacobi2d')
+  n, it = 16384, 1000
+  a = np.random.default_rng(6).random((n, n), dtype=np.float32)
+  prog.set_max_depth(0)
+  deep, timing = prog.run_numpy([a], iterate=it, timed=True)
+  assert timing['max_depth'] == 12
+  for y0, x0 in ((8000, 8000), (it, it), (n - it - 16, n - it - 300)):
+    ys, xs = slice(y0 - it, y0 + 16 + it), slice(x0 - it, x0 + 300 + it)
+    sub = np.ascontiguousarray(a[ys, xs])
+    want = oracle('jacobi2d').run([sub], iterate=it)['t0']
+    assert np.array_equal(deep[0][y0:y0 + 16, x0:x0 + 300],
+                          want[it:it + 16, it:it + 300]), (y0, x0)
+  prog.set_max_depth(8)
+  other = prog.run_numpy([a], iterate=it)[0]
+  prog.set_max_depth(0)
+  assert np.array_equal(deep[0], other)
+  assert deep[0][it:-it, it:-it].std() > 0
+
+
+def test_full_size_cfg5_jacobi3d_512_x200_and_cfg3_blur_16384():
+  """BASELINE configs 5 and 3 at full size against the oracle, every cell."""
+  prog = program('jacobi3d')
+  a = np.random.default_rng(8).random((512, 512, 512), dtype=np.float32)
+  got, timing = prog.run_numpy([a], iterate=200, timed=True)
+  assert timing['max_depth'] == 4
+  want = oracle('jacobi3d').run([a], iterate=200)[prog.spec['outputs'][0]]
+  sl = oracle('jacobi3d').valid_slices((512, 512, 512), 200)
+  assert want[sl].size == 112 ** 3 and np.array_equal(got[0][sl], want[sl])
+  del a, got, want
+  prog = program('blur')
+  b = np.random.default_rng(9).integers(0, 65536, size=(16384, 16384)).astype(np.uint16)
+  got = prog.run_numpy([b], iterate=1)[0]
+  want = oracle('blur').run([b], iterate=1)[prog.spec['outputs'][0]]
+  sl = oracle('blur').valid_slices((16384, 16384), 1)
+  assert np.array_equal(got[sl], want[sl])
+
+
 @pytest.mark.parametrize('app,dims,iterate', [
     ('jacobi2d', [500, 300], '12'), ('blur', [2000, 100], '1'),
     ('denoise2d', [300, 200], '1'), ('heat3d', [60, 50, 40], '3')])
