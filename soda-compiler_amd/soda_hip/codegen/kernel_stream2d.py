@@ -25,7 +25,6 @@ Mapping (gfx950, wave64):
 
 Cost model per cell-update (jacobi2d): 5 VALU lane-ops, 8/depth bytes of HBM.
 """
-import math
 
 from . import spec as specmod
 from .kernel_common import builtin_type, device_expr, tensor_index

@@ -29,7 +29,6 @@ Scope: chains in which every group reads only itself and the LAST instance of
 the previous group (jacobi2d, seidel2d, blur ...); other programs use the
 single-wave form.
 """
-import math
 import re
 
 from . import spec as specmod

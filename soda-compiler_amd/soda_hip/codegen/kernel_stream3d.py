@@ -22,7 +22,7 @@ instead of 8.
 """
 from . import spec as specmod
 from .kernel_common import builtin_type, device_expr, tensor_index
-from .kernel_stream2d import (LANES, WAVES_PER_BLOCK, Instance, NotFusable,
+from .kernel_stream2d import (LANES, WAVES_PER_BLOCK, NotFusable,
                               build_pipeline)
 
 

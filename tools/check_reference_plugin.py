@@ -6,7 +6,6 @@ a drop-in plug-in of the REFERENCE driver.  Builds the reference's own
 reference src/sodac:127 calls `xocl.print_code`, and checks that the kernel text
 equals what this project's own front end produces for the same program."""
 import argparse
-import io
 import os
 import sys
 
