@@ -233,6 +233,11 @@ def run_single(args):
                     kernel_launches=timing['dominant_launches'],
                     algorithmic_bytes_per_update=abytes,
                     updates_per_launch=sum(dom_updates) / len(dom_updates)))
+  # physical HBM rate of the dominant kernel: PMC bytes per launch / its duration
+  traffic = result['roofline']['traffic']
+  if traffic:
+    result['roofline']['hbm_measured_GBps'] = traffic / dom_avg_s / 1e9
+    result['roofline']['hbm_measured_frac'] = traffic / dom_avg_s / 1e9 / HBM_PEAK_GBPS
   for d in din + dout:
     d.free()
   program.close()

@@ -30,16 +30,23 @@ def main():
   stats = newest(os.path.join(src, 'prof_%s' % tag, '*', '*_kernel_stats.csv'))
   shutil.copy(stats, os.path.join(dst, '%s_kernel_stats.csv' % tag))
   traffic = {}
-  for counter, folder in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
-    f = newest(os.path.join(src, folder, '*', '*_counter_collection.csv'))
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-      if r['Counter_Name'] == counter:
-        agg[r['Kernel_Name']].append(float(r['Counter_Value']))
-    for kernel, vals in agg.items():
-      traffic.setdefault(kernel, {})[counter] = dict(
-          launches=len(vals), mean_KiB=sum(vals) / len(vals), min_KiB=min(vals),
-          max_KiB=max(vals))
+  # pmc_fetch / pmc_write hold the passes of the default bench; pmc_fetch_<x> /
+  # pmc_write_<x> those of other workloads (kernel names are unique per program)
+  for counter, prefix in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
+    for folder in sorted(glob.glob(os.path.join(src, prefix + '*'))):
+      if not os.path.isdir(folder):
+        continue
+      f = newest(os.path.join(folder, '*', '*_counter_collection.csv'))
+      agg = collections.defaultdict(list)
+      for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] == counter:
+          agg[r['Kernel_Name']].append(float(r['Counter_Value']))
+      for kernel, vals in agg.items():
+        if kernel.startswith('__amd_rocclr') and folder != os.path.join(src, prefix):
+          continue
+        traffic.setdefault(kernel, {})[counter] = dict(
+            launches=len(vals), mean_KiB=sum(vals) / len(vals), min_KiB=min(vals),
+            max_KiB=max(vals))
   out = {}
   for kernel, c in traffic.items():
     if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
