@@ -124,10 +124,17 @@ def run_slab(engine, plan, arrays, iterate, margins_of, dist, depth_multiple=1):
 
 
 def auto_exchange(own_rows, reach, deepest, iterate):
-  """Iterations between exchanges: a multiple of the deepest fused kernel,
-  about four of them, but never more ghost rows than ~6% of the slab."""
-  e = deepest * 4
-  while e > deepest and e * reach * 2 > max(1, own_rows) * 0.12:
+  """Iterations between exchanges: a multiple of the deepest fused kernel, up to
+  twelve of them, but never more ghost rows than ~15 % of the slab.
+
+  Measured on one MI355X at the slab sizes of 8 and 4 ranks of the 16384^2
+  jacobi2d grid (own rows + 2 E ghost rows, E iterations): 2048 own rows cost
+  9.07 / 8.24 / 8.09 us per iteration at E = 48 / 96 / 144, 4096 own rows 15.97 /
+  14.30 at E = 48 / 96 - the extra ghost rows are cheaper than they look because
+  taller slabs run the fused kernels more efficiently (longer y-chunks, smaller
+  share of pipeline fill), and every exchange avoided saves its latency."""
+  e = deepest * 12
+  while e > deepest and e * reach * 2 > max(1, own_rows) * 0.15:
     e -= deepest
   return max(1, min(e, iterate))
 

@@ -87,5 +87,8 @@ def test_slab_bounds_and_plan():
   # margins: neighbour sides are fully valid, global sides carry the margin
   lo, hi = first.valid_margins(10, lambda k: ((k, k), (k, k)))
   assert (lo, hi) == ([10, 10], [10, 0])
-  assert sdist.auto_exchange(2048, 1, 12, 1000) == 48
+  assert sdist.auto_exchange(2048, 1, 12, 1000) == 144      # 8 ranks of 16384 rows
+  assert sdist.auto_exchange(8192, 1, 12, 1000) == 144
+  assert sdist.auto_exchange(64, 1, 4, 200) == 4            # 8 ranks of 512 planes
   assert sdist.auto_exchange(64, 1, 12, 1000) == 12
+  assert sdist.auto_exchange(2048, 1, 12, 30) == 30

@@ -454,7 +454,7 @@ def test_multi_output_host_buffer_protocol():
 
 @pytest.mark.parametrize('app,dims,world,exchange,iterate', [
     ('jacobi2d', (1500, 611), 2, 12, 30), ('jacobi2d', (1500, 611), 3, 5, 17),
-    ('jacobi2d', (1500, 611), 4, 24, 48),
+    ('jacobi2d', (1500, 611), 4, 24, 48), ('jacobi2d', (900, 1400), 2, 144, 300),
     ('jacobi3d', (130, 70, 96), 2, 8, 20), ('jacobi3d', (67, 45, 120), 3, 4, 13),
     ('heat3d', (100, 64, 90), 2, 12, 24)])
 def test_slab_decomposition_with_the_hip_engine(app, dims, world, exchange, iterate):
