@@ -764,8 +764,12 @@ int soda_hip_sweep_timed(soda_hip_plan* plan, void* const* in, void* const* out,
       if ((rc = launch_one(plan, l, s))) return rc;
   // one event before every launch and one after the last, per repeat
   const size_t per = list.size() + 1;
-  std::vector<hipEvent_t> ev(per * repeats);
-  for (auto& e : ev) HIP_TRY(SODA_HIP_ERR_DEVICE_RUN, hipEventCreate(&e));
+  std::vector<hipEvent_t> ev(per * repeats, nullptr);
+  for (auto& e : ev)
+    if (!rc && hipEventCreate(&e) != hipSuccess) {
+      e = nullptr;
+      rc = fail(SODA_HIP_ERR_DEVICE_RUN, "hipEventCreate failed");
+    }
   for (int r = 0; r < repeats && !rc; ++r) {
     for (size_t i = 0; i < list.size() && !rc; ++i) {
       if (hipEventRecord(ev[r * per + i], s) != hipSuccess)
@@ -808,7 +812,8 @@ int soda_hip_sweep_timed(soda_hip_plan* plan, void* const* in, void* const* out,
                plan->kernels[best].name);
     }
   }
-  for (auto& e : ev) (void)hipEventDestroy(e);
+  for (auto& e : ev)
+    if (e) (void)hipEventDestroy(e);
   return rc;
 }
 
