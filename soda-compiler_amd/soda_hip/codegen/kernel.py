@@ -235,7 +235,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
       for depth in deep:
         options = {k[3:]: v for k, v in fused_options.items()
                    if k in ('wp_rows', 'wp_groups', 'wp_prefetch', 'wp_vgpr_budget', 'wp_split',
-                           'wp_lds_budget', 'wp_waves_per_eu', 'wp_loader',
+                           'wp_lds_budget', 'wp_waves_per_eu', 'wp_loader', 'wp_sched_fence',
                            'wp_ring_prefetch')}
         options.setdefault('groups', min(depth * len(spec['stages']), 4))
         try:

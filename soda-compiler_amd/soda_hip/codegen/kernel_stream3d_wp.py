@@ -28,7 +28,7 @@ from .kernel_stream3d import kernel_name
 
 def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
          max_period=12, vgpr_budget=200, lds_budget=64 * 1024, split=2,
-         waves_per_eu=2, loader=0, ring_prefetch=2):
+         waves_per_eu=3, loader=0, ring_prefetch=2, sched_fence=1):
   """Returns (text, kernel table entry).
 
   split=2: the wavefront is a 32 x 2 grid of lanes; lane (lx, ly) holds columns
@@ -39,13 +39,13 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   cells fetched.  Rows that cross the halves come from one v_permlane32_swap per
   register (tools/permlane_test.hip).
 
-  waves_per_eu=2: the register allocator may not go beyond 256 VGPRs.  Left
-  alone the scheduler hoists the next planes' loads above the current plane's
-  arithmetic in the loading wavefront (its own prefetch, 32 registers per plane);
-  heat3d then needs 274 VGPRs, one workgroup per CU, 814 us per launch - capped,
-  622 us with 24 spilled registers.  (`-amdgpu-sched-strategy=iterative-ilp`
-  finds a 216-register schedule, 506 us, but it is a per-translation-unit,
-  experimental switch.)
+  sched_fence=1, waves_per_eu=3: left alone, the scheduler hoists the NEXT
+  planes' loads above the current plane's arithmetic in the loading wavefront
+  (its own prefetch, 32 fresh registers per plane): jacobi3d 252 VGPRs, heat3d
+  274 (one workgroup per CU, 814 us per launch).  A scheduling fence after each
+  plane's loads keeps them in place (176 / 229 VGPRs) and the occupancy hint asks
+  for three workgroups per CU (168 VGPRs; 9 / 135 spilled registers):
+  jacobi3d 415 -> 356 us per full-size launch, heat3d 601 -> 509 us.
 
   loader=1 (with split=2, EXPERIMENTAL, off): an extra wavefront does nothing but
   stream input plane tiles into an LDS ring with LDS-direct loads
@@ -207,6 +207,10 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
                    'p[%s + x + %d] : (%s)0;' % (inst.ident, s, r, c, c, c,
                                                 row_inside(r), row_off(r), c, T_in))
           line('          } }')
+          if sched_fence:
+            # keep this plane's loads where they are: the scheduler otherwise
+            # hoists the NEXT planes' loads above them into fresh registers
+            line('          __builtin_amdgcn_sched_barrier(0);')
           continue
         if inst.role == 'ring_in':
           s = slot(inst, u, 0)
