@@ -36,6 +36,9 @@ WAVE_GROUPS = -1
 AUTO_WP_VGPRS = 200
 AUTO_WP_GROUPS = 4
 AUTO_WP_BUDGET = 200
+AUTO_WP_RING = 6               # LDS ring slots of the packed form (4 rows in flight)
+AUTO_WP_SQUEEZE_VGPRS = 152
+PACKED_DEEP_DEPTH = 16
 WAVE_PIPELINE_MIN_DEPTH = 4
 # Shallow fused kernels are HBM-bound: their strips start and end on 128-byte
 # lines (kernel_stream2d.geometry, align='full'; +7..10 % measured at depth 1-2,
@@ -157,7 +160,17 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
   parts.append(text)
   notes = []
   if fused and spec['dim'] == 2:
-    wanted = fused_depths(spec, max_depth)
+    wanted = list(fused_depths(spec, max_depth))
+    # one level deeper for programs the packed wave-pipelined form covers: it
+    # is the only form with the registers for it and, fed through the LDS ring,
+    # the only one that gains from it (jacobi2d 16384^2: depth 12 single-wave
+    # 46.0 us per iteration, depth 16 packed + ring 39.5)
+    if (len(wanted) > 1 and max_depth >= DEFAULT_MAX_DEPTH and
+        spec['iterate'] >= PACKED_DEEP_DEPTH and
+        len(spec['inputs']) == len(spec['outputs']) == 1 and
+        (WAVE_GROUPS if wave_groups is None else wave_groups) == -1 and
+        kernel_stream2d_wp.packable(spec)):
+      wanted.append(PACKED_DEEP_DEPTH)
     if depths is not None:
       wanted = sorted(set([1] + [d for d in depths if len(wanted) > 1 or d == 1]))
     for depth in wanted:
@@ -174,7 +187,8 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
         try:
           single = kernel_stream2d.emit(
               spec, depth, **common,
-              **{k: v for k, v in fused_options.items() if k != 'pairs'})
+              **{k: v for k, v in fused_options.items()
+                 if k not in ('pairs', 'ring')})
         except kernel_stream2d.NotFusable as e:
           notes.append('depth %d not fused: %s' % (depth, e))
       want_piped = depth >= WAVE_PIPELINE_MIN_DEPTH and (
@@ -182,21 +196,34 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
               single is None or single[1]['est_vgprs'] > AUTO_WP_VGPRS)))
       if want_piped:
         options = {k: v for k, v in fused_options.items()
-                   if k in ('skip_fill', 'vgpr_budget', 'max_period', 'pairs', 'align')}
+                   if k in ('skip_fill', 'vgpr_budget', 'max_period', 'pairs', 'align',
+                            'ring', 'waves_per_eu')}
         if groups == -1:
           options.setdefault('vgpr_budget', AUTO_WP_BUDGET)
           options.setdefault('pairs', int(kernel_stream2d_wp.packable(spec)))
+          if options['pairs']:
+            # input rows through the LDS ring: no prefetch registers (see
+            # kernel_stream2d_wp.emit); needs 16-byte lanes of 4-byte elements
+            options.setdefault('ring', AUTO_WP_RING)
         try:
           piped = kernel_stream2d_wp.emit(
               spec, depth, groups=AUTO_WP_GROUPS if groups == -1 else groups,
               **common, **options)
+          if (groups == -1 and options.get('ring') and 'waves_per_eu' not in options
+              and 128 < piped[1]['est_vgprs'] <= AUTO_WP_SQUEEZE_VGPRS):
+            # a few registers over four workgroups per CU: let the compiler
+            # spill them (jacobi2d depth 16: 150 -> 128 VGPRs, 12 spilled, +1.6 %)
+            piped = kernel_stream2d_wp.emit(
+                spec, depth, groups=AUTO_WP_GROUPS, waves_per_eu=4, **common,
+                **options)
         except kernel_stream2d.NotFusable as e:
           notes.append('depth %d not wave-pipelined: %s' % (depth, e))
           if single is None and groups > 1:
             try:
               single = kernel_stream2d.emit(
                   spec, depth, **common,
-                  **{k: v for k, v in fused_options.items() if k != 'pairs'})
+                  **{k: v for k, v in fused_options.items()
+                 if k not in ('pairs', 'ring')})
             except kernel_stream2d.NotFusable as e2:
               notes.append('depth %d not fused: %s' % (depth, e2))
       if piped is None and single is None:

@@ -139,6 +139,26 @@ DEV void soda_block_barrier() {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// The same for kernels that keep LDS-direct loads (global_load_lds) in flight
+// across the barrier: a release fence would have to wait for them (they are LDS
+// writes: vmcnt(0)) and undo the prefetch.  Waits for this wavefront's own DS
+// traffic only; the memory clobber keeps the compiler from moving LDS accesses
+// across.  Rows that arrive by LDS-direct load are consumed by the wavefront that
+// issued them, after its own explicit vmcnt wait.
+DEV void soda_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\\n\\ts_barrier" ::: "memory");
+}
+// 16 bytes from LDS through an instruction the compiler does not see as an LDS
+// read: before a visible read of memory that LDS-direct loads write, it waits
+// for ALL of them (vmcnt(0)), whichever slot they target; the kernels wait for
+// exactly the row they need (explicit vmcnt) and then read it with this.
+typedef float soda_f4 __attribute__((ext_vector_type(4)));
+DEV soda_f4 soda_lds_read_f4(const void* p) {
+  soda_f4 v;
+  asm volatile("ds_read_b128 %%0, %%1\\n\\ts_waitcnt lgkmcnt(0)"
+               : "=v"(v) : "v"((unsigned)(unsigned long long)p) : "memory");
+  return v;
+}
 DEV int lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }

@@ -151,8 +151,17 @@ def packable(spec):
 
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
-         max_period=12, vgpr_budget=120, skip_fill=1, pairs=0, align='none'):
+         max_period=12, vgpr_budget=120, skip_fill=1, pairs=0, align='none',
+         ring=0, waves_per_eu=0):
   """Returns (text, kernel table entry).
+
+  ring=N (a divisor of the rotation period, >= 3): the first wavefront does not
+  prefetch input rows into registers; it streams them into an N-slot LDS ring
+  with LDS-direct loads (global_load_lds_dwordx4, N-2 rows in flight, no VGPRs)
+  and reads each row back when its turn comes.  LDS-direct loads cannot be
+  guarded per element, so strips that would overhang the array are moved inside
+  it (they still store only their own columns) and the kernel declares the
+  narrowest array it accepts (min_extent).
 
   pairs=1 (float programs, see packable()): a wavefront streams TWO adjacent
   strips at once, element c of strip A and element c of strip B sharing one
@@ -175,7 +184,12 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   P = 2 if pairs else 1
   if spec['dim'] != 2:
     raise NotFusable('2-D programs only')
-  everything, per_wave, final = build_groups(spec, depth, prefetch, groups)
+  RS = int(ring)
+  PF = RS - 2
+  if RS and (RS < 3 or (C * elem) % 16 or elem != 4):
+    raise NotFusable('input ring: >= 3 slots, 16-byte lanes of 4-byte elements')
+  everything, per_wave, final = build_groups(spec, depth, 0 if RS else prefetch,
+                                             groups)
   geo = geometry(spec, depth, C, chunk_rows, align)
   for inst in everything:
     for src, rel, _ in inst.reads:
@@ -187,6 +201,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   best = None
   for candidate in range(2, max_period + 1, 2):
     if max(i.keep for i in everything) > candidate:
+      continue
+    if RS and candidate % RS:
       continue
     divisors = [d for d in range(1, candidate + 1) if candidate % d == 0]
     padded = [min(d for d in divisors if d >= i.keep) if i.keep else 0
@@ -241,7 +257,6 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
        % (T_in, vec, C, C * elem))
   if pairs:
     line('typedef float pk2 __attribute__((ext_vector_type(2)));')
-    line('typedef float soda_f4 __attribute__((ext_vector_type(4)));')
   # LDS hand-off rows: 16-byte pieces, piece q of lane l at [q][l] (conflict-free)
   pieces = C * P * elem // 16 if pairs else 1
   per_piece = C * P // pieces
@@ -260,10 +275,36 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
       return 'from_lane_below(%s[%d])' % (row, C + j)
     return 'from_lane_above(%s[%d])' % (row, j - C)
 
+  def vmcnt(n):      # s_waitcnt immediate: vmcnt(n), other counters untouched
+    return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14)
+
+  def ring_issue(row_expr, slot_index):
+    line('        { i64 row = %s; if (row > H - 1) row = H - 1;' % row_expr)
+    for h in range(P):
+      line('          __builtin_amdgcn_global_load_lds((const __attribute__(('
+           'address_space(1))) void*)(g_in + row * W + %s), (__attribute__(('
+           'address_space(3))) void*)&in_ring[%d][%d][0], 16, 0, 0);'
+           % ('xb' if h else 'x', slot_index, h))
+    line('        }')
+
   def emit_body(mine, guarded):
     for u in range(period):
       line('      {  // unrolled step %d' % u)
       for inst in mine:
+        if inst.role == 'global_in' and RS:
+          s = slot(inst, u, 0)
+          ring_issue('head + %d' % (u + PF), (u + PF) % RS)
+          # row head+u was issued PF rows ago
+          line('        __builtin_amdgcn_s_waitcnt(%d);  // vmcnt(%d)'
+               % (vmcnt(PF * P), PF * P))
+          for h in range(P):
+            line('        const soda_f4 ring_v%d = soda_lds_read_f4(&in_ring[%d][%d]'
+                 '[lane * %d]);' % (h, u % RS, h, C))
+          for c in range(C):
+            line('        %s[%d][%d] = %s;' % (
+                inst.ident, s, c,
+                'pk2{ring_v0[%d], ring_v1[%d]}' % (c, c) if pairs else 'ring_v0[%d]' % c))
+          continue
         if inst.role == 'global_in':
           s = slot(inst, u, 0)
           line('        { i64 row = head + %d; if (row > H - 1) row = H - 1;' % u)
@@ -340,32 +381,35 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
         if inst.final:
           line('        { const i64 y = head + %d;' % (u - L))
           line('          if (y >= y0 && y < y1) {')
-          line('            %s* q = g_out + y * W + x;' % T_out)
           for half in range(P):
             sel = '[%d]' % half if pairs else ''
             sfx = 'b' if half else ''
-            off = geo['w_out'] * half
-            line('            if (x + %d >= st_lo%s && x + %d <= st_hi%s) { %s v;%s '
-                 '*(%s*)(q + %d) = v; }'
-                 % (off, sfx, off + C, sfx, vec, ''.join(
-                     ' v[%d] = out_row[%d]%s;' % (c, c, sel) for c in range(C)),
-                    vec, off))
-            line('            else {%s }' % ''.join(
-                ' if (x + %d >= st_lo%s && x + %d < st_hi%s) q[%d] = out_row[%d]%s;'
-                % (c + off, sfx, c + off, sfx, c + off, c, sel) for c in range(C)))
+            xv = 'xb' if half else 'x'
+            line('            { %s* q = g_out + y * W + %s;' % (T_out, xv))
+            line('            if (%s >= st_lo%s && %s + %d <= st_hi%s) { %s v;%s '
+                 '*(%s*)q = v; }'
+                 % (xv, sfx, xv, C, sfx, vec, ''.join(
+                     ' v[%d] = out_row[%d]%s;' % (c, c, sel) for c in range(C)), vec))
+            line('            else {%s } }' % ''.join(
+                ' if (%s + %d >= st_lo%s && %s + %d < st_hi%s) q[%d] = out_row[%d]%s;'
+                % (xv, c, sfx, xv, c, sfx, c, c, sel) for c in range(C)))
           line('          } }')
         if skip:
           line('        }')
       line('      }')
-      line('      soda_block_barrier();')
+      line('      %s();' % ('soda_lds_barrier' if RS else 'soda_block_barrier'))
 
   line('template <bool INTERIOR>')
   line('DEV void %s_strip(const soda_hip_args& a, const i64 xs, const i64 x, '
-       'const i64 y0, const i64 y1, const int wave, const int lane,' % name)
+       'const i64 xb, const i64 y0, const i64 y1, const int wave, const int lane,'
+       % name)
+  ring_dims = (P, LANES * C) if RS else (1, 1)
   if pairs:
-    line('    float (*handoff)[2][%d][%d]) {' % (pieces, LANES * 4))
+    line('    float (*handoff)[2][%d][%d], %s (*in_ring)[%d][%d]) {'
+         % (pieces, LANES * 4, T_in, ring_dims[0], ring_dims[1]))
   else:
-    line('    %s (*handoff)[2][%d]) {' % (T_in, LANES * C))
+    line('    %s (*handoff)[2][%d], %s (*in_ring)[%d][%d]) {'
+         % (T_in, LANES * C, T_in, ring_dims[0], ring_dims[1]))
   line('  const i64 W = a.dims[0], H = a.dims[1];')
   line('  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];')
   line('  const i64 st_hi = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];'
@@ -379,7 +423,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
        % (T_in, T_in, index[spec['inputs'][0]['name']]))
   line('  %s* __restrict__ g_out = (%s*)a.tensor[%d];' % (T_out, T_out,
                                                            index[out_name]))
-  line('  (void)g_in; (void)g_out; (void)st_lo; (void)st_hi; (void)W; (void)H;')
+  line('  (void)g_in; (void)g_out; (void)st_lo; (void)st_hi; (void)W; (void)H; '
+       '(void)xb; (void)in_ring;')
   line('  const i64 steps = (y1 - y0) + %d;' % (L + geo['y_lo']))
   prologue_steps = max(i.first_step for i in everything)
   prologue_steps = -(-prologue_steps // period) * period if skip_fill else 0
@@ -395,6 +440,9 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
                                  for c in range(C)))
     line('    i64 head = y0 - %d;' % geo['y_lo'])
     line('    i64 n = 0;')
+    if RS and g == 0:      # the first PF rows of the ring
+      for k in range(PF):
+        ring_issue('head + %d' % k, k)
     if prologue_steps:
       line('    for (; n < %d && n < steps; n += %d, head += %d) {'
            % (prologue_steps, period, period))
@@ -403,16 +451,26 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
     line('    for (; n < steps; n += %d, head += %d) {' % (period, period))
     emit_body(mine, False)
     line('    }')
+    if RS and g == 0:
+      line('    __builtin_amdgcn_s_waitcnt(%d);  // no load may outlive the LDS'
+           % vmcnt(0))
     line('  }')
   line('}')
   line('')
-  line('GLOBAL WG_SIZE(%d) void %s(soda_hip_args a) {' % (groups * LANES, name))
+  occupancy = ''
+  if waves_per_eu > 0:
+    occupancy = ' __attribute__((amdgpu_waves_per_eu(%d, %d)))' % (waves_per_eu,
+                                                                   waves_per_eu)
+  line('GLOBAL WG_SIZE(%d)%s void %s(soda_hip_args a) {' % (groups * LANES, occupancy,
+                                                             name))
   if pairs:
     line('  __attribute__((shared)) float handoff[%d][2][%d][%d];' % (
         max(1, groups - 1), pieces, LANES * 4))
   else:
     line('  __attribute__((shared)) %s handoff[%d][2][%d];' % (
         T_in, max(1, groups - 1), LANES * C))
+  line('  __attribute__((shared)) %s in_ring[%d][%d][%d];' % (
+      T_in, RS if RS else 1, ring_dims[0], ring_dims[1]))
   line('  const int lane = lane_id();')
   line('  const int wave = __builtin_amdgcn_readfirstlane('
        '__builtin_amdgcn_workitem_id_x() >> 6);')
@@ -420,18 +478,32 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   line('  const i64 xs = x_origin + (i64)__builtin_amdgcn_workgroup_id_x() * %d;'
        % (P * geo['w_out']))
   line('  if (xs >= a.box_hi[0]) return;')
-  line('  const i64 x = xs - %d + lane * %d;' % (geo['halo_lo'], C))
   line('  const i64 chunk = a.param[0] > 0 ? a.param[0] : %d;' % chunk_rows)
   line('  const i64 y0 = a.box_lo[1] + (i64)__builtin_amdgcn_workgroup_id_y() * chunk;')
   line('  const i64 y1 = y0 + chunk < a.box_hi[1] ? y0 + chunk : a.box_hi[1];')
-  line('  const bool interior = xs - %d >= 0 && xs - %d + %d <= a.dims[0];'
-       % (geo['halo_lo'], geo['halo_lo'], LANES * C + (P - 1) * geo['w_out']))
-  line('  if (interior) %s_strip<true>(a, xs, x, y0, y1, wave, lane, handoff);' % name)
-  line('  else %s_strip<false>(a, xs, x, y0, y1, wave, lane, handoff);' % name)
+  if RS:
+    # strips that would overhang the array are moved inside it (no guarded loads)
+    for v, start in (('wx', 'xs - %d' % geo['halo_lo']),
+                     ('wxb', 'xs + %d' % (geo['w_out'] - geo['halo_lo']))):
+      line('  i64 %s = %s;' % (v, start))
+      line('  if (%s + %d > a.dims[0]) %s = a.dims[0] - %d;' % (v, LANES * C, v, LANES * C))
+      line('  if (%s < 0) %s = 0;' % (v, v))
+    line('  const i64 x = wx + lane * %d, xb = wxb + lane * %d;' % (C, C))
+    line('  %s_strip<true>(a, xs, x, xb, y0, y1, wave, lane, handoff, in_ring);' % name)
+  else:
+    line('  const i64 x = xs - %d + lane * %d;' % (geo['halo_lo'], C))
+    line('  const i64 xb = x + %d;' % geo['w_out'])
+    line('  const bool interior = xs - %d >= 0 && xs - %d + %d <= a.dims[0];'
+         % (geo['halo_lo'], geo['halo_lo'], LANES * C + (P - 1) * geo['w_out']))
+    line('  if (interior) %s_strip<true>(a, xs, x, xb, y0, y1, wave, lane, handoff, '
+         'in_ring);' % name)
+    line('  else %s_strip<false>(a, xs, x, xb, y0, y1, wave, lane, handoff, in_ring);'
+         % name)
   line('}')
   entry = dict(name=name, kind='fused', depth=depth, stage=-1,
                block=[groups * LANES, 1, 1],
                tile=[P * geo['w_out'], chunk_rows, 1, 1], pairs=int(bool(pairs)),
+               ring=RS, min_extent=[LANES * C, 1] if RS else [0, 0],
                origin_align=geo['origin_align'],
                fill_rows=L + geo['y_lo'], cols=C, prefetch=prefetch, period=period,
                est_vgprs=est_vgprs, groups=groups, w_out=geo['w_out'])

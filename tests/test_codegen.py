@@ -131,6 +131,27 @@ def test_wave_pipelined_forms_compile(options, tmp_path):
                             pairs=1)
 
 
+def test_default_depth_sets():
+  """jacobi2d and seidel2d (plain float programs) get a depth-16 kernel in the
+  packed wave-pipelined form, fed through the LDS ring and therefore limited to
+  arrays at least one strip wide; integer programs stop where they did."""
+  table = kernel.generate(spec_of('jacobi2d', iterate=1000))[1]
+  fused = {k['depth']: k for k in table if k['kind'] == 'fused'}
+  assert sorted(fused) == [1, 2, 4, 8, 12, 16]
+  assert not fused[12].get('groups')
+  k16 = fused[16]
+  assert k16['groups'] == 4 and k16['pairs'] == 1 and k16['ring'] == 6
+  assert k16['min_extent'] == [256, 1] and k16['block'] == [256, 1, 1]
+  table = kernel.generate(spec_of('jacobi2d', iterate=15))[1]
+  assert max(k['depth'] for k in table) == 12
+  table = kernel.generate(spec_of('seidel2d', iterate=100))[1]
+  fused = {k['depth']: k for k in table if k['kind'] == 'fused'}
+  assert sorted(fused) == [1, 2, 4, 8, 12, 16] and fused[12]['ring'] == 6
+  table = kernel.generate(spec_of('blur', iterate=100))[1]
+  assert max(k['depth'] for k in table) == 12 and not any(
+      k.get('ring') for k in table)
+
+
 def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   """Depth-4 3-D kernel: one level per wavefront, 64x32 tiles, declares the
   smallest array it accepts; programs it does not cover keep depth <= 2."""

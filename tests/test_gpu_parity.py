@@ -96,8 +96,8 @@ def test_random_vs_oracle_default_iterate(app):
 
 
 @pytest.mark.parametrize('iterate,max_depth', [
-    (1, 0), (2, 0), (3, 0), (5, 0), (8, 0), (16, 0), (21, 0), (37, 0),
-    (7, 1), (7, 2), (9, 4), (20, 8), (6, -1)])
+    (1, 0), (2, 0), (3, 0), (5, 0), (8, 0), (16, 0), (21, 0), (37, 0), (50, 0),
+    (7, 1), (7, 2), (9, 4), (20, 8), (33, 12), (6, -1)])
 def test_jacobi2d_iterations_and_depths(iterate, max_depth):
   """Temporal blocking: any split of `iterate` into fused depths, and the
   per-stage kernels (max_depth -1), give the same bits."""
@@ -110,6 +110,9 @@ def test_jacobi2d_iterations_and_depths(iterate, max_depth):
     ('jacobi2d', dict(wave_groups=4)),
     ('jacobi2d', dict(wave_groups=4, pairs=1, vgpr_budget=250)),
     ('jacobi2d', dict(wave_groups=2, pairs=1, vgpr_budget=250)),
+    ('jacobi2d', dict(wave_groups=4, pairs=1, vgpr_budget=250, ring=6)),
+    ('jacobi2d', dict(wave_groups=4, vgpr_budget=250, ring=4)),
+    ('seidel2d', dict(wave_groups=4, pairs=1, vgpr_budget=250, ring=6, waves_per_eu=4)),
     ('seidel2d', dict(wave_groups=4, pairs=1, vgpr_budget=250)),
     ('blur', dict(wave_groups=4, vgpr_budget=200))])
 def test_wave_pipelined_generator_forms(app, options):
@@ -117,7 +120,8 @@ def test_wave_pipelined_generator_forms(app, options):
   LDS; two strips packed into v_pk_*_f32 operands) produce the oracle's bits."""
   from soda_hip.codegen import kernel, spec as specmod
   from soda_hip.runtime import host
-  for iterate, shape in ((8, (130, 1300)), (19, (300, 2100)), (9, (64, 64))):
+  for iterate, shape in ((8, (130, 1300)), (19, (300, 2100)), (9, (64, 64)),
+                         (13, (90, 256)), (12, (70, 257)), (21, (50, 511))):
     spec = gpu_util.load_spec(app, iterate=iterate)
     text, table = kernel.generate(spec, **options)
     assert any(k.get('groups') for k in table), [k['name'] for k in table]
@@ -300,24 +304,26 @@ def test_full_size_cfg4_jacobi2d_16384_x1000():
   """BASELINE config 4, the headline workload, at full size: two windows of the
   result (one in the middle, one in the corner of the valid region) are compared
   bit for bit with the oracle run on the sub-grid that holds their whole
-  1000-iteration dependency cone; and the depth-12 schedule agrees with the
-  depth-8 one everywhere."""
+  1000-iteration dependency cone; and the default schedule (62 x depth 16, packed
+  wave-pipelined kernel fed through the LDS ring, + 8) agrees with the depth-12
+  and the depth-8 ones everywhere."""
   prog = program('jacobi2d')
   n, it = 16384, 1000
   a = np.random.default_rng(6).random((n, n), dtype=np.float32)
   prog.set_max_depth(0)
   deep, timing = prog.run_numpy([a], iterate=it, timed=True)
-  assert timing['max_depth'] == 12
+  assert timing['max_depth'] == 16
   for y0, x0 in ((8000, 8000), (it, it), (n - it - 16, n - it - 300)):
     ys, xs = slice(y0 - it, y0 + 16 + it), slice(x0 - it, x0 + 300 + it)
     sub = np.ascontiguousarray(a[ys, xs])
     want = oracle('jacobi2d').run([sub], iterate=it)['t0']
     assert np.array_equal(deep[0][y0:y0 + 16, x0:x0 + 300],
                           want[it:it + 16, it:it + 300]), (y0, x0)
-  prog.set_max_depth(8)
-  other = prog.run_numpy([a], iterate=it)[0]
+  for limit in (12, 8):
+    prog.set_max_depth(limit)
+    other = prog.run_numpy([a], iterate=it)[0]
+    assert np.array_equal(deep[0], other), limit
   prog.set_max_depth(0)
-  assert np.array_equal(deep[0], other)
   assert deep[0][it:-it, it:-it].std() > 0
 
 

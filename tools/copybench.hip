@@ -64,6 +64,35 @@ __global__ void __launch_bounds__(64 * WPB) copy_strips(const float* __restrict_
   }
 }
 
+// rows through LDS-direct loads (global_load_lds_dwordx4: no registers), PF rows
+// in flight per wavefront, one wavefront per 256 columns, 4 wavefronts per block
+template <int PF>
+__global__ void __launch_bounds__(256) copy_rows_lds(const float* __restrict__ in, float* __restrict__ out, long W, long H, long chunk) {
+  __attribute__((shared)) float ring[4][PF + 1][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long x = ((long)blockIdx.x * 4 + wave) * 256 + lane * 4;
+  if (x >= W) return;
+  const long y0 = (long)blockIdx.y * chunk, y1 = y0 + chunk < H ? y0 + chunk : H;
+  auto issue = [&](long y, int slot) {
+    if (y > H - 1) y = H - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + y * W + x),
+                                     (__attribute__((address_space(3))) void*)&ring[wave][slot][0], 16, 0, 0);
+  };
+#pragma unroll
+  for (int p = 0; p < PF; ++p) issue(y0 + p, p);
+  for (long y = y0; y < y1; y += PF + 1) {
+#pragma unroll
+    for (int p = 0; p < PF + 1; ++p) {
+      issue(y + p + PF, (p + PF) % (PF + 1));
+      // row y+p was issued PF loads ago: at most PF may still be in flight
+      __builtin_amdgcn_s_waitcnt((PF & 15) | (7 << 4) | (15 << 8) | ((PF >> 4) << 14));
+      const float4v v = *(const float4v*)&ring[wave][p][lane * 4];
+      if (y + p < y1) *(float4v*)(out + (y + p) * W + x) = v;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+}
+
 template <typename F> void timeit(const char* name, size_t bytes, F f) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   f(); CK(hipDeviceSynchronize());
@@ -90,6 +119,13 @@ int main() {
     snprintf(nm, sizeof nm, "rows plain pf6 chunk=%ld", chunk); timeit(nm, bytes, [&] { copy_rows<0,0,6><<<grid,256>>>(a, b, W, H, chunk); });
     snprintf(nm, sizeof nm, "rows nt-ld nt-st pf6 chunk=%ld", chunk); timeit(nm, bytes, [&] { copy_rows<1,1,6><<<grid,256>>>(a, b, W, H, chunk); });
     snprintf(nm, sizeof nm, "rows nt-st pf6 chunk=%ld", chunk); timeit(nm, bytes, [&] { copy_rows<0,1,6><<<grid,256>>>(a, b, W, H, chunk); });
+  }
+  for (long chunk : {256L, 1024L}) {
+    dim3 grid((unsigned)(W / 1024), (unsigned)((H + chunk - 1) / chunk));
+    char nm[96];
+    snprintf(nm, sizeof nm, "rows lds-direct pf3 chunk=%ld", chunk); timeit(nm, bytes, [&] { copy_rows_lds<3><<<grid,256>>>(a, b, W, H, chunk); });
+    snprintf(nm, sizeof nm, "rows lds-direct pf7 chunk=%ld", chunk); timeit(nm, bytes, [&] { copy_rows_lds<7><<<grid,256>>>(a, b, W, H, chunk); });
+    snprintf(nm, sizeof nm, "rows lds-direct pf15 chunk=%ld", chunk); timeit(nm, bytes, [&] { copy_rows_lds<15><<<grid,256>>>(a, b, W, H, chunk); });
   }
   struct G { int w_out, halo_lo; };
   for (G g : {G{256, 0}, G{248, 4}, G{232, 12}, G{224, 16}, G{224, 0}, G{192, 32}}) {
