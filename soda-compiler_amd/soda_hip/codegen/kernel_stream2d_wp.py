@@ -10,14 +10,14 @@ seven waves fit.  This is the reference's own structure one level up: SODA chain
 compute modules with FIFOs (reference src/soda/dataflow.py:122-346); the modules
 are wavefronts and the FIFOs are LDS rows.
 
-Status: EXPERIMENTAL, off by default (kernel.WAVE_GROUPS = 0).  Measured on
-MI355X, jacobi2d 16384x16384, depth 12 (tools/tune.py): single-wave 543-555 us,
-this form 570-590 us, this form with packed pairs (below) 543-570 us.  The
-single-wave kernel already issues ~92 % of what the VALU sustains for its
-instruction mix at two waves per SIMD (tools/valubench.hip: 42.6 T lane-ops/s for
-the scalar jacobi row, 50-56 T for the packed one at 2-3 waves per SIMD), so the
-extra occupancy buys nothing and the barrier per row costs a little.  Both forms
-are bit-exact against the oracle (tools/check_variant.py).
+Status: `kernel.generate` chooses this form where the single-wave form needs more
+than 200 VGPRs or cannot be built (seidel2d from depth 12, blur from depth 8), and
+for the depth-16 kernel of plain float programs (packed pairs + LDS ring, see
+emit()).  Measured on MI355X, 16384x16384 (tools/tune.py): jacobi2d depth 12
+single-wave 543-555 us per launch, this form 570-590 us, packed 545-570 us, packed
+with the LDS ring 524 us; depth 16 packed with the ring 632 us = 39.5 us per
+iteration against 46.0.  All forms are bit-exact against the oracle
+(tests/test_gpu_parity.py, tools/check_variant.py).
 
 Everything else is as in kernel_stream2d: lane l holds C consecutive columns,
 x-neighbours by DPP wave shifts, windows rotated by unrolling, overlapped

@@ -132,7 +132,7 @@ def test_random_program(seed):
 
 @pytest.mark.parametrize('seed', range(int(os.environ.get('SODA_RANDOM_DEEP_SEEDS', '16'))))
 def test_random_program_many_iterations(seed):
-  """The same generator with `iterate` 8..14: deep fused kernels, among them
+  """The same generator with `iterate` 8..20: deep fused kernels, among them
   the wave-pipelined and packed forms the generator picks for chains that do not
   fit one wavefront's registers."""
   rng = np.random.default_rng(5000 + seed)
@@ -140,6 +140,6 @@ def test_random_program_many_iterations(seed):
     text, dim, dtype, iterate = random_program(rng, seed)
     if dim == 2 and 'input %s: in1' % dtype not in text:
       break
-  deep = int(rng.integers(8, 15))
+  deep = int(rng.integers(8, 21))
   text = text.replace('iterate: %d\n' % iterate, 'iterate: %d\n' % deep)
   run_case(text, dim, deep, seed, (400, 700), rng)
