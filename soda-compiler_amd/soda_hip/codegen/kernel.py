@@ -201,9 +201,10 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
         if groups == -1:
           options.setdefault('vgpr_budget', AUTO_WP_BUDGET)
           options.setdefault('pairs', int(kernel_stream2d_wp.packable(spec)))
-          if options['pairs']:
+          lane_bytes = common['cols'] * specmod.ELEM_SIZE[spec['inputs'][0]['c_type']]
+          if lane_bytes == 16:
             # input rows through the LDS ring: no prefetch registers (see
-            # kernel_stream2d_wp.emit); needs 16-byte lanes of 4-byte elements
+            # kernel_stream2d_wp.emit); needs 16-byte lanes
             options.setdefault('ring', AUTO_WP_RING)
         try:
           piped = kernel_stream2d_wp.emit(

@@ -186,8 +186,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
     raise NotFusable('2-D programs only')
   RS = int(ring)
   PF = RS - 2
-  if RS and (RS < 3 or (C * elem) % 16 or elem != 4):
-    raise NotFusable('input ring: >= 3 slots, 16-byte lanes of 4-byte elements')
+  if RS and (RS < 3 or C * elem != 16):
+    raise NotFusable('input ring: >= 3 slots, 16-byte lanes')
   everything, per_wave, final = build_groups(spec, depth, 0 if RS else prefetch,
                                              groups)
   geo = geometry(spec, depth, C, chunk_rows, align)
@@ -298,8 +298,9 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
           line('        __builtin_amdgcn_s_waitcnt(%d);  // vmcnt(%d)'
                % (vmcnt(PF * P), PF * P))
           for h in range(P):
-            line('        const soda_f4 ring_v%d = soda_lds_read_f4(&in_ring[%d][%d]'
-                 '[lane * %d]);' % (h, u % RS, h, C))
+            line('        const %s_lds ring_v%d = __builtin_bit_cast(%s_lds, '
+                 'soda_lds_read_f4(&in_ring[%d][%d][lane * %d]));'
+                 % (vec, h, vec, u % RS, h, C))
           for c in range(C):
             line('        %s[%d][%d] = %s;' % (
                 inst.ident, s, c,

@@ -134,7 +134,8 @@ def test_wave_pipelined_forms_compile(options, tmp_path):
 def test_default_depth_sets():
   """jacobi2d and seidel2d (plain float programs) get a depth-16 kernel in the
   packed wave-pipelined form, fed through the LDS ring and therefore limited to
-  arrays at least one strip wide; integer programs stop where they did."""
+  arrays at least one strip wide; integer programs stop at depth 12 (their
+  wave-pipelined kernels use the ring too)."""
   table = kernel.generate(spec_of('jacobi2d', iterate=1000))[1]
   fused = {k['depth']: k for k in table if k['kind'] == 'fused'}
   assert sorted(fused) == [1, 2, 4, 8, 12, 16]
@@ -148,8 +149,10 @@ def test_default_depth_sets():
   fused = {k['depth']: k for k in table if k['kind'] == 'fused'}
   assert sorted(fused) == [1, 2, 4, 8, 12, 16] and fused[12]['ring'] == 6
   table = kernel.generate(spec_of('blur', iterate=100))[1]
-  assert max(k['depth'] for k in table) == 12 and not any(
-      k.get('ring') for k in table)
+  fused = {k['depth']: k for k in table if k['kind'] == 'fused'}
+  assert sorted(fused) == [1, 2, 4, 8, 12]       # integer program: no depth 16
+  assert fused[8]['groups'] == 4 and fused[8]['ring'] == 6 and not fused[8]['pairs']
+  assert not fused[4].get('groups')
 
 
 def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
