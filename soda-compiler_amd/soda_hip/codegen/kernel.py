@@ -39,6 +39,10 @@ AUTO_WP_BUDGET = 200
 AUTO_WP_RING = 6               # LDS ring slots of the packed form (4 rows in flight)
 AUTO_WP_SQUEEZE_VGPRS = 152
 PACKED_DEEP_DEPTH = 16
+# packable programs: the packed + ring form also replaces the single-wave form
+# from this depth on (jacobi2d 16384^2 per launch: depth 12 570 vs 617 us, depth 8
+# 501 vs 470 us - the single-wave form stays below)
+PACKED_FROM_DEPTH = 12
 WAVE_PIPELINE_MIN_DEPTH = 4
 # Shallow fused kernels are HBM-bound: their strips start and end on 128-byte
 # lines (kernel_stream2d.geometry, align='full'; +7..10 % measured at depth 1-2,
@@ -193,7 +197,8 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
           notes.append('depth %d not fused: %s' % (depth, e))
       want_piped = depth >= WAVE_PIPELINE_MIN_DEPTH and (
           groups > 1 or (groups == -1 and (
-              single is None or single[1]['est_vgprs'] > AUTO_WP_VGPRS)))
+              single is None or single[1]['est_vgprs'] > AUTO_WP_VGPRS or
+              (depth >= PACKED_FROM_DEPTH and kernel_stream2d_wp.packable(spec)))))
       if want_piped:
         options = {k: v for k, v in fused_options.items()
                    if k in ('skip_fill', 'vgpr_budget', 'max_period', 'pairs', 'align',

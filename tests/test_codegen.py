@@ -139,7 +139,7 @@ def test_default_depth_sets():
   table = kernel.generate(spec_of('jacobi2d', iterate=1000))[1]
   fused = {k['depth']: k for k in table if k['kind'] == 'fused'}
   assert sorted(fused) == [1, 2, 4, 8, 12, 16]
-  assert not fused[12].get('groups')
+  assert fused[12]['groups'] == 4 and fused[12]['pairs'] and not fused[8].get('groups')
   k16 = fused[16]
   assert k16['groups'] == 4 and k16['pairs'] == 1 and k16['ring'] == 6
   assert k16['min_extent'] == [256, 1] and k16['block'] == [256, 1, 1]
