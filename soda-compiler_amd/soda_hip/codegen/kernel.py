@@ -192,7 +192,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
           single = kernel_stream2d.emit(
               spec, depth, **common,
               **{k: v for k, v in fused_options.items()
-                 if k not in ('pairs', 'ring')})
+                 if k not in ('pairs', 'ring', 'dppadd', 'split', 'sync')})
         except kernel_stream2d.NotFusable as e:
           notes.append('depth %d not fused: %s' % (depth, e))
       want_piped = depth >= WAVE_PIPELINE_MIN_DEPTH and (
@@ -202,23 +202,43 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
       if want_piped:
         options = {k: v for k, v in fused_options.items()
                    if k in ('skip_fill', 'vgpr_budget', 'max_period', 'pairs', 'align',
-                            'ring', 'waves_per_eu')}
+                            'ring', 'waves_per_eu', 'dppadd', 'split', 'sync')}
         if groups == -1:
           options.setdefault('vgpr_budget', AUTO_WP_BUDGET)
-          options.setdefault('pairs', int(kernel_stream2d_wp.packable(spec)))
           lane_bytes = common['cols'] * specmod.ELEM_SIZE[spec['inputs'][0]['c_type']]
           if lane_bytes == 16:
             # input rows through the LDS ring: no prefetch registers (see
             # kernel_stream2d_wp.emit); needs 16-byte lanes
             options.setdefault('ring', AUTO_WP_RING)
+          # packable programs: one 512-column strip per wavefront, its two halves
+          # sharing register pairs (pairs=2; jacobi2d depth 16 per launch on
+          # 16384^2: 597 us against 627 us for two 256-column strips, pairs=1)
+          options.setdefault('pairs', 0 if not kernel_stream2d_wp.packable(spec)
+                             else 2 if options.get('ring') else 1)
+          # pairs=1: lane-crossing operands as scalar DPP adds (22 instead of 24
+          # VALU instructions per jacobi2d level-row: depth 16 627 -> 610 us)
+          options.setdefault('dppadd', int(options['pairs'] == 1))
         try:
           piped = kernel_stream2d_wp.emit(
               spec, depth, groups=AUTO_WP_GROUPS if groups == -1 else groups,
               **common, **options)
-          if (groups == -1 and options.get('ring') and 'waves_per_eu' not in options
-              and 128 < piped[1]['est_vgprs'] <= AUTO_WP_SQUEEZE_VGPRS):
-            # a few registers over four workgroups per CU: let the compiler
-            # spill them (jacobi2d depth 16: 150 -> 128 VGPRs, 12 spilled, +1.6 %)
+          squeeze = (groups == -1 and options.get('ring') and
+                     'waves_per_eu' not in options and
+                     128 < piped[1]['est_vgprs'] <= AUTO_WP_SQUEEZE_VGPRS)
+          if squeeze and options.get('pairs') == 2 and options['ring'] == AUTO_WP_RING \
+              and 'max_period' not in options:
+            # a few registers over four workgroups per CU: cap them at 128.  In
+            # the wide form that pays only together with a 12-slot ring (10 rows
+            # in flight) unrolled over 12 rows: jacobi2d depth 16, 16384^2, per
+            # launch 578 us uncapped with ring 6, 830 us capped with ring 6,
+            # 560 us capped with ring 12.
+            piped = kernel_stream2d_wp.emit(
+                spec, depth, groups=AUTO_WP_GROUPS, waves_per_eu=4, **common,
+                **dict(options, ring=2 * AUTO_WP_RING, max_period=2 * AUTO_WP_RING))
+          elif squeeze and not options.get('pairs') == 2 and not options.get('dppadd'):
+            # two-strip form without scalar DPP adds: let the compiler spill them
+            # (jacobi2d depth 16: 150 -> 128 VGPRs, 12 spilled, +1.6 %; with
+            # scalar DPP adds the cap spills 45 and loses 60 %: not then)
             piped = kernel_stream2d_wp.emit(
                 spec, depth, groups=AUTO_WP_GROUPS, waves_per_eu=4, **common,
                 **options)
@@ -229,7 +249,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
               single = kernel_stream2d.emit(
                   spec, depth, **common,
                   **{k: v for k, v in fused_options.items()
-                 if k not in ('pairs', 'ring')})
+                 if k not in ('pairs', 'ring', 'dppadd', 'split', 'sync')})
             except kernel_stream2d.NotFusable as e2:
               notes.append('depth %d not fused: %s' % (depth, e2))
       if piped is None and single is None:

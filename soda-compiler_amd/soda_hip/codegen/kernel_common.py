@@ -215,6 +215,52 @@ template <typename T> DEV T from_lane_below_bp(T v) { return lane_neighbour_bp<T
 template <typename T> DEV T from_lane_above_bp(T v) { return lane_neighbour_bp<T, false>(v); }
 template <typename T> DEV T from_lane_below(T v) { return lane_neighbour<T, true>(v); }
 template <typename T> DEV T from_lane_above(T v) { return lane_neighbour<T, false>(v); }
+// Packed pairs (kernel_stream2d_wp, pairs=1): the neighbour lane's pair as two
+// SCALARS.  v_pk_add_f32 cannot take a DPP operand, so `pair + shifted pair`
+// costs one packed add and two v_mov_b32_dpp; as two scalar adds the compiler
+// folds each shift into its add (v_add_f32_dpp): two instructions instead of
+// three, same IEEE operations.
+typedef float pk2 __attribute__((ext_vector_type(2)));
+struct pk2_shifted {
+  float lo, hi;
+  __attribute__((device)) inline __attribute__((always_inline)) operator pk2() const { return pk2{lo, hi}; }
+};
+DEV pk2_shifted pk_from_lane_below(pk2 v) {
+  return pk2_shifted{from_lane_below(v[0]), from_lane_below(v[1])};
+}
+DEV pk2_shifted pk_from_lane_above(pk2 v) {
+  return pk2_shifted{from_lane_above(v[0]), from_lane_above(v[1])};
+}
+// Wide strips (pairs=2): a lane holds 2C consecutive columns, the pair's low
+// half the first C and its high half the last C.  The column before the lane's
+// first one is the lower lane's last (high half); the column before the high
+// half's first one is the lane's own low half - and mirrored upwards.
+DEV pk2_shifted pk_wide_below(pk2 v) {
+  return pk2_shifted{from_lane_below(v[1]), v[0]};
+}
+DEV pk2_shifted pk_wide_above(pk2 v) {
+  return pk2_shifted{v[1], from_lane_above(v[0])};
+}
+// The two scalar results go through an empty asm so that instruction selection
+// cannot put them back together as one packed operation on assembled operands.
+DEV pk2 pk_of_scalars(float lo, float hi) {
+  asm("" : "+v"(lo));
+  asm("" : "+v"(hi));
+  return pk2{lo, hi};
+}
+#define SODA_PK_SHIFTED_OP(OP)                                                  \
+  DEV pk2 operator OP(pk2 a, pk2_shifted b) { return pk_of_scalars(a[0] OP b.lo, a[1] OP b.hi); } \
+  DEV pk2 operator OP(pk2_shifted a, pk2 b) { return pk_of_scalars(a.lo OP b[0], a.hi OP b[1]); } \
+  DEV pk2 operator OP(pk2_shifted a, pk2_shifted b) { return pk_of_scalars(a.lo OP b.lo, a.hi OP b.hi); } \
+  DEV pk2 operator OP(pk2_shifted a, float b) { return pk_of_scalars(a.lo OP b, a.hi OP b); } \
+  DEV pk2 operator OP(float a, pk2_shifted b) { return pk_of_scalars(a OP b.lo, a OP b.hi); }
+SODA_PK_SHIFTED_OP(+)
+SODA_PK_SHIFTED_OP(-)
+SODA_PK_SHIFTED_OP(*)
+SODA_PK_SHIFTED_OP(/)
+#undef SODA_PK_SHIFTED_OP
+DEV pk2 operator-(pk2_shifted a) { return pk2{-a.lo, -a.hi}; }
+DEV pk2 operator+(pk2_shifted a) { return pk2{a.lo, a.hi}; }
 '''
 
 

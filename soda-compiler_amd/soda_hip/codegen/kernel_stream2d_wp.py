@@ -36,7 +36,7 @@ from .kernel_common import builtin_type, device_expr, tensor_index
 from .kernel_stream2d import LANES, Instance, NotFusable, geometry, kernel_name
 
 
-def build_groups(spec, depth, prefetch, groups, loader=False):
+def build_groups(spec, depth, prefetch, groups, loader=False, split=None, sync=1):
   """Stage instances of `depth` iterations cut into `groups` wavefronts; the
   streamed dimension is the last one (rows in 2-D, planes in 3-D).
 
@@ -71,6 +71,13 @@ def build_groups(spec, depth, prefetch, groups, loader=False):
                      % (len(stages), groups))
   # contiguous groups of (nearly) equal size: equal VALU work per wavefront
   bounds = [round(i * len(stages) / groups) for i in range(groups + 1)]
+  if split:
+    # explicit number of stage instances per wavefront (the first and the last
+    # wavefront also load / store: fewer levels there balance the four)
+    if len(split) != groups or sum(split) != len(stages) or min(split) < 1:
+      raise NotFusable('split %r does not cut %d stage instances into %d groups'
+                       % (split, len(stages), groups))
+    bounds = [sum(split[:i]) for i in range(groups + 1)]
   for g in range(groups):
     for inst in stages[bounds[g]:bounds[g + 1]]:
       inst.group = g
@@ -105,13 +112,14 @@ def build_groups(spec, depth, prefetch, groups, loader=False):
         src = copies[id(src)]
       reads.append((src, rel, name))
     inst.reads = reads
-  # lags, in execution order; a hand-off arrives one step after it was produced
+  # lags, in execution order; a hand-off arrives one barrier interval (`sync`
+  # steps) after it was produced
   source.lag = 0
   for inst in stages:
     lag = None
     for src, rel, _ in inst.reads:
       if src.role in ('lds_in', 'ring_in'):
-        src.lag = src.origin.lag + 1
+        src.lag = src.origin.lag + (sync if src.role == 'lds_in' else 1)
       v = src.lag + rel[axis] + (prefetch if src is source else 0)
       lag = v if lag is None else max(lag, v)
     inst.lag = lag
@@ -152,8 +160,22 @@ def packable(spec):
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
          max_period=12, vgpr_budget=120, skip_fill=1, pairs=0, align='none',
-         ring=0, waves_per_eu=0):
+         ring=0, waves_per_eu=0, dppadd=0, split=None, sync=1):
   """Returns (text, kernel table entry).
+
+  pairs=2 (needs the ring): ONE strip of 2 x 64 x C columns per wavefront; a
+  lane holds 2C consecutive columns, the first C in the low halves of its pairs
+  and the last C in the high halves.  Same instruction count as pairs=1 with
+  dppadd (the two operands per row that cross a half are two scalar adds, one of
+  them DPP), but the x halo is paid once per 512 columns instead of per 256
+  (jacobi2d depth 16: 480 of 512 columns kept against 448).
+
+  sync=S: one workgroup barrier per S streamed rows instead of one per row; a
+  hand-off slot then holds S rows and arrives S steps after it was produced
+  (S must divide half the rotation period so that slot parity repeats).
+
+  dppadd=1 (with pairs): lane-crossing operands stay two scalars so that each
+  shift folds into a scalar add (kernel_common: pk2_shifted).
 
   ring=N (a divisor of the rotation period, >= 3): the first wavefront does not
   prefetch input rows into registers; it streams them into an N-slot LDS ring
@@ -182,15 +204,24 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   if pairs and (C * elem) % 16:
     raise NotFusable('packed form: whole 16-byte vectors per lane')
   P = 2 if pairs else 1
+  wide = int(pairs) == 2
   if spec['dim'] != 2:
     raise NotFusable('2-D programs only')
   RS = int(ring)
   PF = RS - 2
   if RS and (RS < 3 or C * elem != 16):
     raise NotFusable('input ring: >= 3 slots, 16-byte lanes')
+  if wide and not RS:
+    raise NotFusable('wide strips come through the input ring')
+  if isinstance(split, str):
+    split = [int(v) for v in split.split('/')]
   everything, per_wave, final = build_groups(spec, depth, 0 if RS else prefetch,
-                                             groups)
+                                             groups, split=split, sync=sync)
+  S = int(sync)
   geo = geometry(spec, depth, C, chunk_rows, align)
+  if wide:      # the second half adds 64 x C columns, all of them output
+    geo['w_out'] += LANES * C
+  strip_cols = LANES * C * (2 if wide else 1)
   for inst in everything:
     for src, rel, _ in inst.reads:
       if abs(rel[0]) > C:
@@ -203,6 +234,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
     if max(i.keep for i in everything) > candidate:
       continue
     if RS and candidate % RS:
+      continue
+    if candidate % (2 * S):
       continue
     divisors = [d for d in range(1, candidate + 1) if candidate % d == 0]
     padded = [min(d for d in divisors if d >= i.keep) if i.keep else 0
@@ -244,7 +277,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   line('// fused depth-%d kernel, wave-pipelined: %d wavefronts per strip, rotation '
        'period %d,' % (depth, groups, period))
   line('// strip = %d columns (%d out + halo %d/%d), prefetch %d rows, ~%d VGPRs'
-       % (LANES * C, geo['w_out'], geo['halo_lo'], geo['halo_hi'], prefetch,
+       % (strip_cols, geo['w_out'], geo['halo_lo'], geo['halo_hi'], prefetch,
           est_vgprs))
   for g, mine in enumerate(per_wave):
     for inst in mine:
@@ -271,9 +304,13 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
     j = c + rel[0]
     if 0 <= j < C:
       return '%s[%d]' % (row, j)
+    if wide:
+      return 'pk_wide_%s(%s[%d])' % (('below', row, C + j) if j < 0 else
+                                     ('above', row, j - C))
+    shift = 'pk_from_lane' if pairs and dppadd else 'from_lane'
     if j < 0:
-      return 'from_lane_below(%s[%d])' % (row, C + j)
-    return 'from_lane_above(%s[%d])' % (row, j - C)
+      return '%s_below(%s[%d])' % (shift, row, C + j)
+    return '%s_above(%s[%d])' % (shift, row, j - C)
 
   def vmcnt(n):      # s_waitcnt immediate: vmcnt(n), other counters untouched
     return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14)
@@ -284,7 +321,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
       line('          __builtin_amdgcn_global_load_lds((const __attribute__(('
            'address_space(1))) void*)(g_in + row * W + %s), (__attribute__(('
            'address_space(3))) void*)&in_ring[%d][%d][0], 16, 0, 0);'
-           % ('xb' if h else 'x', slot_index, h))
+           % (('x - lane * %d + %d' % (C, h * LANES * C)) if wide else
+              ('xb' if h else 'x'), slot_index, h))
     line('        }')
 
   def emit_body(mine, guarded):
@@ -299,8 +337,9 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
                % (vmcnt(PF * P), PF * P))
           for h in range(P):
             line('        const %s_lds ring_v%d = __builtin_bit_cast(%s_lds, '
-                 'soda_lds_read_f4(&in_ring[%d][%d][lane * %d]));'
-                 % (vec, h, vec, u % RS, h, C))
+                 'soda_lds_read_f4(&in_ring[%d][%d][0] + lane * %d + %d));'
+                 % (vec, h, vec, u % RS, 0 if wide else h, C * (2 if wide else 1),
+                    C * h if wide else 0))
           for c in range(C):
             line('        %s[%d][%d] = %s;' % (
                 inst.ident, s, c,
@@ -333,14 +372,14 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
           # written by the previous wavefront one step ago: the other slot
           if pairs:
             for q in range(pieces):
-              line('        { const soda_f4 v = *(const soda_f4*)&handoff[%d][%d][%d][lane * 4];%s }'
-                   % (inst.handoff, (u + 1) % 2, q, ''.join(
+              line('        { const soda_f4 v = *(const soda_f4*)&handoff[%d][%d][%d][%d][lane * 4];%s }'
+                   % (inst.handoff, (u // S + 1) % 2, u % S, q, ''.join(
                        ' %s[%d][%d] = pk2{v[%d], v[%d]};' % (
                            inst.ident, s, q * 2 + j, 2 * j, 2 * j + 1)
                        for j in range(2))))
             continue
-          line('        { const %s_lds v = *(const %s_lds*)&handoff[%d][%d][lane * %d];%s }'
-               % (vec, vec, inst.handoff, (u + 1) % 2, C, ''.join(
+          line('        { const %s_lds v = *(const %s_lds*)&handoff[%d][%d][%d][lane * %d];%s }'
+               % (vec, vec, inst.handoff, (u // S + 1) % 2, u % S, C, ''.join(
                    ' %s[%d][%d] = v[%d];' % (inst.ident, s, c, c) for c in range(C))))
           continue
         stage = inst.stage
@@ -371,20 +410,20 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
                 device_expr(stage['expr']), load)))
         if inst.role == 'lds_out' and pairs:
           for q in range(pieces):
-            line('        { soda_f4 v;%s *(soda_f4*)&handoff[%d][%d][%d][lane * 4] = v; }' % (
+            line('        { soda_f4 v;%s *(soda_f4*)&handoff[%d][%d][%d][%d][lane * 4] = v; }' % (
                 ''.join(' v[%d] = out_row[%d][0]; v[%d] = out_row[%d][1];' % (
                     2 * j, q * 2 + j, 2 * j + 1, q * 2 + j) for j in range(2)),
-                inst.handoff, u % 2, q))
+                inst.handoff, (u // S) % 2, u % S, q))
         elif inst.role == 'lds_out':
-          line('        { %s_lds v;%s *(%s_lds*)&handoff[%d][%d][lane * %d] = v; }' % (
+          line('        { %s_lds v;%s *(%s_lds*)&handoff[%d][%d][%d][lane * %d] = v; }' % (
               vec, ''.join(' v[%d] = out_row[%d];' % (c, c) for c in range(C)),
-              vec, inst.handoff, u % 2, C))
+              vec, inst.handoff, (u // S) % 2, u % S, C))
         if inst.final:
           line('        { const i64 y = head + %d;' % (u - L))
           line('          if (y >= y0 && y < y1) {')
           for half in range(P):
             sel = '[%d]' % half if pairs else ''
-            sfx = 'b' if half else ''
+            sfx = 'b' if half and not wide else ''
             xv = 'xb' if half else 'x'
             line('            { %s* q = g_out + y * W + %s;' % (T_out, xv))
             line('            if (%s >= st_lo%s && %s + %d <= st_hi%s) { %s v;%s '
@@ -398,7 +437,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
         if skip:
           line('        }')
       line('      }')
-      line('      %s();' % ('soda_lds_barrier' if RS else 'soda_block_barrier'))
+      if (u + 1) % S == 0:
+        line('      %s();' % ('soda_lds_barrier' if RS else 'soda_block_barrier'))
 
   line('template <bool INTERIOR>')
   line('DEV void %s_strip(const soda_hip_args& a, const i64 xs, const i64 x, '
@@ -406,16 +446,16 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
        % name)
   ring_dims = (P, LANES * C) if RS else (1, 1)
   if pairs:
-    line('    float (*handoff)[2][%d][%d], %s (*in_ring)[%d][%d]) {'
-         % (pieces, LANES * 4, T_in, ring_dims[0], ring_dims[1]))
+    line('    float (*handoff)[2][%d][%d][%d], %s (*in_ring)[%d][%d]) {'
+         % (S, pieces, LANES * 4, T_in, ring_dims[0], ring_dims[1]))
   else:
-    line('    %s (*handoff)[2][%d], %s (*in_ring)[%d][%d]) {'
-         % (T_in, LANES * C, T_in, ring_dims[0], ring_dims[1]))
+    line('    %s (*handoff)[2][%d][%d], %s (*in_ring)[%d][%d]) {'
+         % (T_in, S, LANES * C, T_in, ring_dims[0], ring_dims[1]))
   line('  const i64 W = a.dims[0], H = a.dims[1];')
   line('  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];')
   line('  const i64 st_hi = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];'
        % (geo['w_out'], geo['w_out']))
-  if pairs:   # the second strip starts where the first one ends
+  if pairs and not wide:   # the second strip starts where the first one ends
     line('  const i64 st_lob = xs + %d;' % geo['w_out'])
     line('  const i64 st_hib = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];'
          % (2 * geo['w_out'], 2 * geo['w_out']))
@@ -465,19 +505,20 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   line('GLOBAL WG_SIZE(%d)%s void %s(soda_hip_args a) {' % (groups * LANES, occupancy,
                                                              name))
   if pairs:
-    line('  __attribute__((shared)) float handoff[%d][2][%d][%d];' % (
-        max(1, groups - 1), pieces, LANES * 4))
+    line('  __attribute__((shared)) float handoff[%d][2][%d][%d][%d];' % (
+        max(1, groups - 1), S, pieces, LANES * 4))
   else:
-    line('  __attribute__((shared)) %s handoff[%d][2][%d];' % (
-        T_in, max(1, groups - 1), LANES * C))
+    line('  __attribute__((shared)) %s handoff[%d][2][%d][%d];' % (
+        T_in, max(1, groups - 1), S, LANES * C))
   line('  __attribute__((shared)) %s in_ring[%d][%d][%d];' % (
       T_in, RS if RS else 1, ring_dims[0], ring_dims[1]))
   line('  const int lane = lane_id();')
   line('  const int wave = __builtin_amdgcn_readfirstlane('
        '__builtin_amdgcn_workitem_id_x() >> 6);')
   line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % geo['origin_align'])
+  tile_cols = geo['w_out'] * (1 if wide or not pairs else 2)
   line('  const i64 xs = x_origin + (i64)__builtin_amdgcn_workgroup_id_x() * %d;'
-       % (P * geo['w_out']))
+       % tile_cols)
   line('  if (xs >= a.box_hi[0]) return;')
   line('  const i64 chunk = a.param[0] > 0 ? a.param[0] : %d;' % chunk_rows)
   line('  const i64 y0 = a.box_lo[1] + (i64)__builtin_amdgcn_workgroup_id_y() * chunk;')
@@ -486,10 +527,15 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
     # strips that would overhang the array are moved inside it (no guarded loads)
     for v, start in (('wx', 'xs - %d' % geo['halo_lo']),
                      ('wxb', 'xs + %d' % (geo['w_out'] - geo['halo_lo']))):
+      if wide and v == 'wxb':
+        continue
       line('  i64 %s = %s;' % (v, start))
-      line('  if (%s + %d > a.dims[0]) %s = a.dims[0] - %d;' % (v, LANES * C, v, LANES * C))
+      line('  if (%s + %d > a.dims[0]) %s = a.dims[0] - %d;' % (v, strip_cols, v, strip_cols))
       line('  if (%s < 0) %s = 0;' % (v, v))
-    line('  const i64 x = wx + lane * %d, xb = wxb + lane * %d;' % (C, C))
+    if wide:    # the lane's 2C columns; xb = where its high halves start
+      line('  const i64 x = wx + lane * %d, xb = x + %d;' % (2 * C, C))
+    else:
+      line('  const i64 x = wx + lane * %d, xb = wxb + lane * %d;' % (C, C))
     line('  %s_strip<true>(a, xs, x, xb, y0, y1, wave, lane, handoff, in_ring);' % name)
   else:
     line('  const i64 x = xs - %d + lane * %d;' % (geo['halo_lo'], C))
@@ -503,9 +549,9 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   line('}')
   entry = dict(name=name, kind='fused', depth=depth, stage=-1,
                block=[groups * LANES, 1, 1],
-               tile=[P * geo['w_out'], chunk_rows, 1, 1], pairs=int(bool(pairs)),
-               ring=RS, min_extent=[LANES * C, 1] if RS else [0, 0],
+               tile=[tile_cols, chunk_rows, 1, 1], pairs=int(pairs),
+               ring=RS, min_extent=[strip_cols, 1] if RS else [0, 0],
                origin_align=geo['origin_align'],
                fill_rows=L + geo['y_lo'], cols=C, prefetch=prefetch, period=period,
-               est_vgprs=est_vgprs, groups=groups, w_out=geo['w_out'])
+               est_vgprs=est_vgprs, groups=groups, w_out=geo['w_out'], sync=S)
   return '\n'.join(o) + '\n', entry

@@ -105,8 +105,11 @@ def test_every_sample_compiles_for_gfx950(app, tmp_path):
   assert len(stages) == len(specmod.inline_pointwise(spec)['stages'])
 
 
-@pytest.mark.parametrize('options', [dict(wave_groups=4), dict(wave_groups=4, pairs=1,
-                                                                vgpr_budget=250)])
+@pytest.mark.parametrize('options', [
+    dict(wave_groups=4), dict(wave_groups=4, pairs=1, vgpr_budget=250),
+    dict(wave_groups=4, pairs=1, vgpr_budget=250, dppadd=1, sync=3),
+    dict(wave_groups=4, pairs=2, vgpr_budget=250, ring=6),
+    dict(wave_groups=4, pairs=2, vgpr_budget=250, ring=12, max_period=12, sync=2)])
 def test_wave_pipelined_forms_compile(options, tmp_path):
   """The experimental wave-pipelined form of the fused 2-D kernel (one wavefront
   per group of levels, LDS hand-off) and its packed-pair variant build for
@@ -117,9 +120,16 @@ def test_wave_pipelined_forms_compile(options, tmp_path):
   fused = [k for k in table if k['kind'] == 'fused' and k['depth'] == 8]
   assert fused and fused[0]['groups'] == 4 and fused[0]['block'] == [256, 1, 1]
   assert fused[0]['pairs'] == options.get('pairs', 0)
-  if options.get('pairs'):
-    assert fused[0]['tile'][0] == 2 * fused[0]['w_out']
-    assert 'pk2' in text
+  if options.get('pairs') == 1:     # two strips per wavefront
+    assert fused[0]['tile'][0] == 2 * fused[0]['w_out'] == 2 * (256 - 16)
+  if options.get('pairs') == 2:     # one strip of twice the width
+    assert fused[0]['tile'][0] == fused[0]['w_out'] == 512 - 16
+    assert fused[0]['min_extent'] == [512, 1] and 'pk_wide_below(' in text
+  if options.get('dppadd'):
+    assert 'pk_from_lane_below(' in text
+  assert fused[0].get('sync', 1) == options.get('sync', 1)
+  if options.get('sync', 1) > 1:
+    assert fused[0]['period'] % (2 * options['sync']) == 0
   out = tmp_path / 'wp.hsaco'
   kernel.compile_to_code_object(text, str(out))
   assert open(out, 'rb').read(4) == b'\x7fELF'
@@ -129,6 +139,8 @@ def test_wave_pipelined_forms_compile(options, tmp_path):
   with pytest.raises(kernel_stream2d.NotFusable):
     kernel_stream2d_wp.emit(specmod.inline_pointwise(spec_of('blur', iterate=8)), 8,
                             pairs=1)
+  with pytest.raises(kernel_stream2d.NotFusable):    # wide strips need the ring
+    kernel_stream2d_wp.emit(spec, 8, pairs=2)
 
 
 def test_default_depth_sets():
@@ -141,13 +153,15 @@ def test_default_depth_sets():
   assert sorted(fused) == [1, 2, 4, 8, 12, 16]
   assert fused[12]['groups'] == 4 and fused[12]['pairs'] and not fused[8].get('groups')
   k16 = fused[16]
-  assert k16['groups'] == 4 and k16['pairs'] == 1 and k16['ring'] == 6
-  assert k16['min_extent'] == [256, 1] and k16['block'] == [256, 1, 1]
+  # wide strips (512 columns per wavefront), 12-slot ring, four workgroups per CU
+  assert k16['groups'] == 4 and k16['pairs'] == 2 and k16['ring'] == 12
+  assert k16['min_extent'] == [512, 1] and k16['block'] == [256, 1, 1]
+  assert k16['tile'][0] == 480 and fused[12]['ring'] == 6
   table = kernel.generate(spec_of('jacobi2d', iterate=15))[1]
   assert max(k['depth'] for k in table) == 12
   table = kernel.generate(spec_of('seidel2d', iterate=100))[1]
   fused = {k['depth']: k for k in table if k['kind'] == 'fused'}
-  assert sorted(fused) == [1, 2, 4, 8, 12, 16] and fused[12]['ring'] == 6
+  assert sorted(fused) == [1, 2, 4, 8, 12, 16] and fused[16]['ring'] == 6
   table = kernel.generate(spec_of('blur', iterate=100))[1]
   fused = {k['depth']: k for k in table if k['kind'] == 'fused'}
   assert sorted(fused) == [1, 2, 4, 8, 12]       # integer program: no depth 16

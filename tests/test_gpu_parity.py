@@ -114,14 +114,28 @@ def test_jacobi2d_iterations_and_depths(iterate, max_depth):
     ('jacobi2d', dict(wave_groups=4, vgpr_budget=250, ring=4)),
     ('seidel2d', dict(wave_groups=4, pairs=1, vgpr_budget=250, ring=6, waves_per_eu=4)),
     ('seidel2d', dict(wave_groups=4, pairs=1, vgpr_budget=250)),
-    ('blur', dict(wave_groups=4, vgpr_budget=200))])
+    ('blur', dict(wave_groups=4, vgpr_budget=200)),
+    # scalar DPP adds for the lane-crossing operands of packed pairs
+    ('jacobi2d', dict(wave_groups=4, pairs=1, vgpr_budget=250, ring=6, dppadd=1)),
+    # wide strips: 512 columns per wavefront, halves interleaved inside a lane
+    ('jacobi2d', dict(wave_groups=4, pairs=2, vgpr_budget=250, ring=6)),
+    ('jacobi2d', dict(wave_groups=4, pairs=2, vgpr_budget=250, ring=12, max_period=12,
+                      waves_per_eu=4)),
+    ('seidel2d', dict(wave_groups=4, pairs=2, vgpr_budget=250, ring=12, max_period=12)),
+    # one barrier per 3 (2) streamed rows
+    ('jacobi2d', dict(wave_groups=4, pairs=2, vgpr_budget=250, ring=6, sync=3)),
+    ('jacobi2d', dict(wave_groups=4, vgpr_budget=250, sync=3)),
+    ('seidel2d', dict(wave_groups=2, pairs=2, vgpr_budget=250, ring=12, max_period=12,
+                      sync=2)),
+    ('blur', dict(wave_groups=4, vgpr_budget=200, sync=3))])
 def test_wave_pipelined_generator_forms(app, options):
   """The experimental forms of the fused 2-D kernel (wavefront pipeline through
   LDS; two strips packed into v_pk_*_f32 operands) produce the oracle's bits."""
   from soda_hip.codegen import kernel, spec as specmod
   from soda_hip.runtime import host
   for iterate, shape in ((8, (130, 1300)), (19, (300, 2100)), (9, (64, 64)),
-                         (13, (90, 256)), (12, (70, 257)), (21, (50, 511))):
+                         (13, (90, 256)), (12, (70, 257)), (21, (50, 511)),
+                         (31, (80, 512)), (10, (40, 513)), (24, (75, 995))):
     spec = gpu_util.load_spec(app, iterate=iterate)
     text, table = kernel.generate(spec, **options)
     assert any(k.get('groups') for k in table), [k['name'] for k in table]
