@@ -105,9 +105,10 @@ def cpu_baseline(spec, dims, budget_s):
   for threads in sorted({max(1, quota // 2), quota, min(logical, quota * 2),
                          min(logical, quota * 4)}):
     orc.set_threads(threads)
-    t, u = orc.time_iterations(inputs, 3, warmup=1)
-    if best is None or u / t > best[1]:
-      best = (threads, u / t, t / 3)
+    for _ in range(2):      # shared hosts are noisy: best of two short trials
+      t, u = orc.time_iterations(inputs, 3, warmup=1)
+      if best is None or u / t > best[1]:
+        best = (threads, u / t, t / 3)
   threads, _, per = best
   orc.set_threads(threads)
   n = int(max(8, min(400, budget_s / max(per, 1e-6))))
