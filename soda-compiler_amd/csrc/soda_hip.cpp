@@ -295,10 +295,11 @@ int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
     if (kd.kind != SODA_HIP_KERNEL_FUSED ||
         (plan->max_depth > 0 && kd.depth > plan->max_depth))
       continue;
-    // kernels without a guarded path: only arrays at least one tile large
+    // kernels without a guarded path: only arrays at least one tile large; the
+    // 3-D ones index inside a plane with 32 bits (2-D ones are 64-bit throughout)
     if (kd.min_extent[0] > 0 &&
         (dims[0] < kd.min_extent[0] || (p.dim > 1 && dims[1] < kd.min_extent[1]) ||
-         (p.dim > 1 && dims[0] * dims[1] >= (int64_t(1) << 30))))
+         (p.dim > 2 && dims[0] * dims[1] >= (int64_t(1) << 30))))
       continue;
     fused.push_back((int)k);
   }

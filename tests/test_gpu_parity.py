@@ -557,10 +557,11 @@ def test_denormals_signed_zeros_and_infinities():
 
 def test_grid_beyond_2_to_31_elements():
   """64-bit indexing: 50000 x 43000 floats = 2.15e9 cells (8.6 GB per array),
-  13 iterations (one depth-12 + one depth-1 launch).  Bands of rows at the top,
+  29 iterations (one depth-16, one depth-12 - both fed by LDS-direct loads - and
+  one depth-1 launch).  Bands of rows at the top,
   just below and above the 2^31-element boundary and at the bottom are compared
   with the oracle run on sub-grids containing their dependency cones."""
-  w, h, it = 50000, 43000, 13
+  w, h, it = 50000, 43000, 29
   assert w * h > 2 ** 31
   prog = program('jacobi2d')
   cols = (np.arange(w, dtype=np.int64) * 7 % 1013).astype(np.float32) / np.float32(1013)
