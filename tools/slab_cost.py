@@ -25,7 +25,7 @@ blob = os.path.join(ROOT, 'soda-compiler_amd', 'blobs', app + '.hsaco')
 prog = host.open_program(blob=blob, spec=spec)
 r = max(spec['radius']['lo'][-1], spec['radius']['hi'][-1], 1)
 rng = np.random.default_rng(1)
-for world in (1, 2, 4, 8):
+for world in [int(v) for v in os.environ.get('SLAB_WORLDS', '1,2,4,8').split(',')]:
   own = H // world
   for e, depth in variants:
     ghosts = 0 if world == 1 else 2 * e * r
