@@ -67,6 +67,10 @@ struct soda_hip_plan {
   std::vector<int> resident_blocks;  // per kernel: workgroups the chip holds at once
   int max_depth = 0;
   int chunk_rows_override = 0;       // SODA_HIP_CHUNK_ROWS, for tuning
+  // shortest chunk the launcher considers: small grids need many short chunks to
+  // reach every CU (jacobi3d 128^3, depth 4: 67 us per launch with 32-plane
+  // chunks)
+  int chunk_rows_min = 8;
   // scratch: [0, n_outputs) ping-pong partner of the outputs,
   // then one per non-output stage (only used by per-stage kernels)
   std::vector<void*> scratch;
@@ -222,7 +226,9 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
       for (int e = 0; e < dim - 1; ++e) inner *= out->grid[e];
       const int64_t resident = std::max(1, plan->resident_blocks[k]);
       int64_t best = tile, best_cost = -1;
-      for (int64_t chunk = 32; chunk <= std::max<int64_t>(32, std::min<int64_t>(extent, 4096));
+      const int64_t shortest = plan->chunk_rows_min;   // 8; SODA_HIP_CHUNK_MIN
+      for (int64_t chunk = shortest;
+           chunk <= std::max<int64_t>(shortest, std::min<int64_t>(extent, 4096));
            chunk += 4) {
         const int64_t blocks = inner * ((extent + chunk - 1) / chunk);
         const int64_t rounds = (blocks + resident - 1) / resident;
@@ -706,6 +712,8 @@ int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* progra
     }
   }
   if (const char* env = getenv("SODA_HIP_CHUNK_ROWS")) pl->chunk_rows_override = atoi(env);
+  if (const char* env = getenv("SODA_HIP_CHUNK_MIN"))
+    pl->chunk_rows_min = std::max(4, atoi(env));
   *plan = pl;
   return 0;
 }
