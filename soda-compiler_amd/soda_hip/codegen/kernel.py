@@ -55,6 +55,7 @@ DEEP_3D_DEPTHS = (4,)
 # depth-4 launch against 2 x 374 us at depth 2, heat3d (15) 622 us against
 # 2 x 411 us; heavier programs are VALU-bound at depth 2 already
 DEEP_3D_MAX_WEIGHT = 20
+PACKED_3D_SQUEEZE_WEIGHT = 10
 # ... and only programs that are light on arithmetic (denoise2d, ~70 weighted
 # operations per cell, is VALU-bound at depth 1 and loses 19 % to the narrower
 # aligned strips; blur 20, sobel2d 28, jacobi2d 5 gain)
@@ -289,8 +290,19 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
         options = {k[3:]: v for k, v in fused_options.items()
                    if k in ('wp_rows', 'wp_groups', 'wp_prefetch', 'wp_vgpr_budget', 'wp_split',
                            'wp_lds_budget', 'wp_waves_per_eu', 'wp_loader', 'wp_sched_fence',
-                           'wp_ring_prefetch')}
+                           'wp_ring_prefetch', 'wp_pairs')}
         options.setdefault('groups', min(depth * len(spec['stages']), 4))
+        if options.get('split', 2) == 2 and not options.get('loader') and \
+            options.get('rows', 16) % 2 == 0 and kernel_stream2d_wp.packable(spec):
+          # packed pair-rows (v_pk_*_f32).  Light programs are bounded by memory
+          # and keep three workgroups per CU (jacobi3d 512^3, per launch: 302 ->
+          # 297 us); heavier ones need the registers (heat3d: 459 us scalar, 629 us
+          # packed at three workgroups per CU with 360 spilled registers, 383 us
+          # packed at the 230 VGPRs the compiler asks for)
+          options.setdefault('pairs', 1)
+          if options['pairs']:
+            options.setdefault('waves_per_eu', 3 if arithmetic_weight(spec) <=
+                               PACKED_3D_SQUEEZE_WEIGHT else 0)
         try:
           ftext, entry = kernel_stream3d_wp.emit(spec, depth, **options)
         except kernel_stream2d.NotFusable as e:

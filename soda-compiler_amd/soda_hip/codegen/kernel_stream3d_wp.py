@@ -22,13 +22,13 @@ single-wave form.
 from . import spec as specmod
 from .kernel_common import builtin_type, device_expr, tensor_index
 from .kernel_stream2d import LANES, NotFusable
-from .kernel_stream2d_wp import build_groups
+from .kernel_stream2d_wp import build_groups, packable
 from .kernel_stream3d import kernel_name
 
 
 def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
          max_period=12, vgpr_budget=200, lds_budget=64 * 1024, split=2,
-         waves_per_eu=3, loader=0, ring_prefetch=2, sched_fence=1):
+         waves_per_eu=3, loader=0, ring_prefetch=2, sched_fence=1, pairs=0):
   """Returns (text, kernel table entry).
 
   split=2: the wavefront is a 32 x 2 grid of lanes; lane (lx, ly) holds columns
@@ -46,6 +46,17 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   plane's loads keeps them in place (176 / 229 VGPRs) and the occupancy hint asks
   for three workgroups per CU (168 VGPRs; 9 / 135 spilled registers):
   jacobi3d 415 -> 356 us per full-size launch, heat3d 601 -> 509 us.
+
+  pairs=1 (split=2, float programs of + - * /, kernel_stream2d_wp.packable): tile
+  rows r and r + R/2 of a lane share a 64-bit register pair, so the arithmetic is
+  v_pk_add_f32 / v_pk_mul_f32 on R/2 pair-rows.  y-neighbours of a pair-row are
+  the next pair-row except at the two seams (row R/2 - 1 -> R/2 is the low half
+  meeting its own high half, rows -1 and R come from the other 32-lane half as
+  before): those operands are two scalars (kernel_common: pk2_shifted) and so are
+  the lane-crossing x-neighbours, each shift folded into its scalar add.  Loads
+  and stores address rows, so the first wavefront spreads each loaded row over
+  the halves of R/2 pairs and the last one gathers them again (register moves
+  only there); hand-offs keep the pair layout (16 bytes per lane and pair-row).
 
   loader=1 (with split=2, EXPERIMENTAL, off): an extra wavefront does nothing but
   stream input plane tiles into an LDS ring with LDS-direct loads
@@ -71,6 +82,18 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   LX = LANES // split          # lanes along x
   TR = split * R               # tile rows
   loader = 1 if (loader and split == 2) else 0
+  pairs = int(bool(pairs))
+  if pairs and (split != 2 or R % 2 or loader or C * 2 * elem != 16):
+    raise NotFusable('packed 3-D form: two row blocks, even R, 2 columns, no loader')
+  if pairs and not packable(spec):
+    raise NotFusable('packed form: float programs of + - * / only')
+  RP = R // 2 if pairs else R      # register rows per lane (pair-rows when packed)
+
+  def cell(ident, s, r, c):
+    """Register holding tile row r, column c of window slot s."""
+    if pairs:
+      return '%s[%d][%d][%d][%d]' % (ident, s, r % RP, c, r // RP)
+    return '%s[%d][%d][%d]' % (ident, s, r, c)
   PF = ring_prefetch
   RS = PF + 2                  # ring slots: PF in flight, one being read, one free
   everything, per_wave, final = build_groups(spec, depth, prefetch, groups,
@@ -156,7 +179,31 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   def slot(inst, u, back):
     return (u - back) % inst.keep
 
+  def operand_pk(reader, src, rel, u, p, c):
+    """Packed form: the operand of pair-row p (tile rows p and p + RP)."""
+    back = reader.lag - src.lag - rel[2]
+    assert 0 <= back < src.keep, (reader.ident, src.ident, rel, back, src.keep)
+    s = slot(src, u, back)
+    j = c + rel[0]
+    jj = j if 0 <= j < C else (C + j if j < 0 else j - C)
+    shift = None if 0 <= j < C else ('below' if j < 0 else 'above')
+    pp = p + rel[1]
+    if 0 <= pp < RP:
+      whole = '%s[%d][%d][%d]' % (src.ident, s, pp, jj)
+      return whole if shift is None else 'pk_from_lane_%s(%s)' % (shift, whole)
+    if pp < 0:     # low half: rows above the lane's block; high half: low halves
+      lo = 'xa_%s_%d_%d[%d]' % (src.ident, s, R + pp, jj)
+      hi = '%s[%d][%d][%d][0]' % (src.ident, s, RP + pp, jj)
+    else:          # low half: the high halves; high half: rows below the block
+      lo = '%s[%d][%d][%d][1]' % (src.ident, s, pp - RP, jj)
+      hi = 'xb_%s_%d_%d[%d]' % (src.ident, s, pp - RP, jj)
+    if shift is not None:
+      lo, hi = ('from_lane_%s(%s)' % (shift, v) for v in (lo, hi))
+    return 'pk2_shifted{%s, %s}' % (lo, hi)
+
   def operand(reader, src, rel, u, r, c):
+    if pairs:
+      return operand_pk(reader, src, rel, u, r, c)
     back = reader.lag - src.lag - rel[2]
     assert 0 <= back < src.keep, (reader.ident, src.ident, rel, back, src.keep)
     rr = r + rel[1]
@@ -198,13 +245,13 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
             address = '(p + %s + x)' % row_off(r) if split == 1 else \
                 '((const char*)(p + %d * W) + lane_byte)' % r
             line('            { const %s v = *(const %s*)%s;%s }' % (
-                vec, vec, address, ''.join(' %s[%d][%d][%d] = v[%d];' % (
-                    inst.ident, s, r, c, c) for c in range(C))))
+                vec, vec, address, ''.join(' %s = v[%d];' % (
+                    cell(inst.ident, s, r, c), c) for c in range(C))))
           line('          } else {')
           for r in range(R):
             for c in range(C):
-              line('            %s[%d][%d][%d] = (x + %d >= 0 && x + %d < W%s) ? '
-                   'p[%s + x + %d] : (%s)0;' % (inst.ident, s, r, c, c, c,
+              line('            %s = (x + %d >= 0 && x + %d < W%s) ? '
+                   'p[%s + x + %d] : (%s)0;' % (cell(inst.ident, s, r, c), c, c,
                                                 row_inside(r), row_off(r), c, T_in))
           line('          } }')
           if sched_fence:
@@ -222,6 +269,14 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
                          ' %s[%d][%d][%d] = v[%d];' % (inst.ident, s, r, c, c)
                          for c in range(C))))
           continue
+        if inst.role == 'lds_in' and pairs:
+          s = slot(inst, u, 0)
+          for q in range(RP):
+            line('        { const soda_f4 v = *(const soda_f4*)&handoff[%d][%d][%d]'
+                 '[lane * 4];%s }' % (inst.handoff, (u + 1) % 2, q, ''.join(
+                     ' %s[%d][%d][%d] = pk2{v[%d], v[%d]};' % (
+                         inst.ident, s, q, c, 2 * c, 2 * c + 1) for c in range(C))))
+          continue
         if inst.role == 'lds_in':
           s = slot(inst, u, 0)
           for r in range(R):
@@ -232,19 +287,19 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
                          for c in range(C))))
           continue
         stage = inst.stage
-        ctype = builtin_type(inst.c_type)
+        ctype = 'pk2' if pairs else builtin_type(inst.c_type)
         by_name = {(n, rel): src for src, rel, n in inst.reads}
         direct = inst.keep == 0
         if direct:
-          line('        %s out_tile[%d][%d];' % (ctype, R, C))
+          line('        %s out_tile[%d][%d];' % (ctype, RP, C))
           if inst.role == 'lds_out':   # rows outside the dependency cone: zeros
-            for r in range(R):
-              line('        ' + ' '.join('out_tile[%d][%d] = 0;' % (r, c)
-                                         for c in range(C)))
+            for r in range(RP):
+              line('        ' + ' '.join('out_tile[%d][%d] = %s;' % (
+                  r, c, 'pk2{0.0f, 0.0f}' if pairs else '0') for c in range(C)))
         # rows whose whole dependency cone lies inside the tile (with two row
         # blocks every lane computes all its rows: the halves run in lock step)
         blo, bhi = stage_boxes[inst.iteration][stage['name']]
-        rows_needed = range(-blo[1], R - bhi[1]) if split == 1 else range(R)
+        rows_needed = range(-blo[1], R - bhi[1]) if split == 1 else range(RP)
         line('        {')
         if split == 2:
           above, below = set(), set()
@@ -253,20 +308,28 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
             for r in rows_needed:
               if r + rel[1] < 0:
                 above.add((src.ident, sl, R + r + rel[1]))
-              elif r + rel[1] >= R:
-                below.add((src.ident, sl, r + rel[1] - R))
+              elif r + rel[1] >= RP:     # (packed: the high halves go past row R)
+                below.add((src.ident, sl, r + rel[1] - RP))
           above, below = sorted(above), sorted(below)
           for n in range(max(len(above), len(below))):
             ia, sa, ka = above[n] if n < len(above) else (None, 0, 0)
             ib, sb, kb = below[n] if n < len(below) else (None, 0, 0)
-            last = '%s[%d][%d]' % (ia, sa, ka) if ia else '%s[%d][%d]' % (ib, sb, kb)
-            first = '%s[%d][%d]' % (ib, sb, kb) if ib else last
+            if pairs:     # the rows as scalars: halves of the pairs that hold them
+              last = '%s[%d][%d]' % (ia, sa, ka % RP) if ia else \
+                  '%s[%d][%d]' % (ib, sb, kb % RP)
+              first = '%s[%d][%d]' % (ib, sb, kb % RP) if ib else last
+              half_last = '[%d]' % ((ka if ia else kb) // RP)
+              half_first = '[%d]' % (kb // RP) if ib else half_last
+            else:
+              last = '%s[%d][%d]' % (ia, sa, ka) if ia else '%s[%d][%d]' % (ib, sb, kb)
+              first = '%s[%d][%d]' % (ib, sb, kb) if ib else last
+              half_last = half_first = ''
             na = 'xa_%s_%d_%d' % (ia, sa, ka) if ia else 'xa_unused%d' % n
             nb = 'xb_%s_%d_%d' % (ib, sb, kb) if ib else 'xb_unused%d' % n
             line('        %s %s[%d], %s[%d];' % (T_in, na, C, nb, C))
             for c in range(C):
-              line('        rows_across_halves(%s[%d], %s[%d], %s[%d], %s[%d]);'
-                   % (first, c, last, c, na, c, nb, c))
+              line('        rows_across_halves(%s[%d]%s, %s[%d]%s, %s[%d], %s[%d]);'
+                   % (first, c, half_first, last, c, half_last, na, c, nb, c))
             if not ia:
               line('        (void)%s;' % na)
             if not ib:
@@ -290,7 +353,15 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
               line('        %s = %s;' % (target, specmod.substitute_loads(
                   device_expr(stage['expr']), load)))
         line('        }')
-        if inst.role == 'lds_out':
+        if inst.role == 'lds_out' and pairs:
+          for q in range(RP):
+            src_row = ('out_tile[%d]' % q) if direct else \
+                '%s[%d][%d]' % (inst.ident, slot(inst, u, 0), q)
+            line('        { soda_f4 v;%s *(soda_f4*)&handoff[%d][%d][%d][lane * 4] = v; }'
+                 % (''.join(' v[%d] = %s[%d][0]; v[%d] = %s[%d][1];' % (
+                     2 * c, src_row, c, 2 * c + 1, src_row, c) for c in range(C)),
+                    inst.handoff, u % 2, q))
+        elif inst.role == 'lds_out':
           for r in range(R):
             src_row = ('out_tile[%d]' % r) if direct else \
                 '%s[%d][%d]' % (inst.ident, slot(inst, u, 0), r)
@@ -316,13 +387,16 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
               line('            }')
             else:   # per-lane predicates computed once, outside the plane loop
               line('            if (%d >= st_r0 && %d < st_r1) {' % (r, r))
+              def out(r, c):
+                return 'out_tile[%d][%d][%d]' % (r % RP, c, r // RP) if pairs else \
+                    'out_tile[%d][%d]' % (r, c)
               line('              if (st_full) { %s v;%s *(%s*)((char*)(q + %d * W) + '
                    'lane_byte) = v; }' % (
-                       vec, ''.join(' v[%d] = out_tile[%d][%d];' % (c, r, c)
+                       vec, ''.join(' v[%d] = %s;' % (c, out(r, c))
                                     for c in range(C)), vec, r))
               line('              else {%s }' % ''.join(
-                  ' if (st_col%d) q[%s + x + %d] = out_tile[%d][%d];'
-                  % (c, row_off(r), c, r, c) for c in range(C)))
+                  ' if (st_col%d) q[%s + x + %d] = %s;'
+                  % (c, row_off(r), c, out(r, c)) for c in range(C)))
               line('            }')
           line('          } }')
       line('      }')
@@ -333,7 +407,8 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
        'const i64 yb, const i64 wx, const i64 wy, const i64 z0, const i64 z1, '
        'const int wave, const int lane,' % name)
   line('    %s (*handoff)[2][%d][%d], %s (*in_ring)[%d][%d]) {'
-       % (T_in, R, LANES * C, T_in, TR if loader else 1, LX * C if loader else 1))
+       % (T_in, RP, LANES * C * (2 if pairs else 1), T_in, TR if loader else 1,
+          LX * C if loader else 1))
   line('  const i64 W = a.dims[0], H = a.dims[1], D = a.dims[2];')
   line('  const i64 plane = W * H;')
   line('  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];')
@@ -414,11 +489,12 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
                                    g + loader))
     for inst in mine:
       if inst.keep:
-        line('    %s %s[%d][%d][%d];' % (builtin_type(inst.c_type), inst.ident,
-                                         inst.keep, R, C))
+        line('    %s %s[%d][%d][%d];' % ('pk2' if pairs else builtin_type(inst.c_type),
+                                         inst.ident, inst.keep, RP, C))
         for k in range(inst.keep):
-          for r in range(R):
-            line('    ' + ' '.join('%s[%d][%d][%d] = 0;' % (inst.ident, k, r, c)
+          for r in range(RP):
+            line('    ' + ' '.join('%s[%d][%d][%d] = %s;' % (
+                inst.ident, k, r, c, 'pk2{0.0f, 0.0f}' if pairs else '0')
                                    for c in range(C)))
     line('    i64 head = z0 - %d;' % lo[2])
     line('    for (i64 n = 0; n < steps; n += %d, head += %d) {' % (period, period))
@@ -434,7 +510,7 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   line('GLOBAL WG_SIZE(%d)%s void %s(soda_hip_args a) {'
        % ((groups + loader) * LANES, occupancy, name))
   line('  __attribute__((shared)) %s handoff[%d][2][%d][%d];' % (
-      T_in, max(1, groups - 1), R, LANES * C))
+      T_in, max(1, groups - 1), RP, LANES * C * (2 if pairs else 1)))
   line('  __attribute__((shared)) %s in_ring[%d][%d][%d];' % (
       T_in, RS if loader else 1, TR if loader else 1, LX * C if loader else 1))
   line('  const int lane = lane_id();')
@@ -479,5 +555,6 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
                fill_rows=L + lo[2], cols=C, rows=R, prefetch=prefetch,
                period=period, est_vgprs=est_vgprs, w_out=w_out, r_out=r_out,
                groups=groups, lds_bytes=lds_bytes, split=split, loader=loader,
+               pairs=pairs,
                min_extent=[LX * C, TR] if split == 2 else [0, 0])
   return '\n'.join(o) + '\n', entry

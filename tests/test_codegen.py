@@ -179,6 +179,10 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   assert k4[0]['min_extent'] == [64, 32] and k4[0]['tile'][:2] == [56, 24]
   assert k4[0]['lds_bytes'] <= 64 * 1024
   assert 'v_permlane32_swap' in text or 'rows_across_halves' in text
+  # float program of + - * /: packed pair-rows, seams as scalar pairs
+  assert k4[0]['pairs'] == 1 and 'pk2_shifted{' in text
+  scalar = kernel.generate(spec, wp_pairs=0)[1]
+  assert [k['pairs'] for k in scalar if k['depth'] == 4] == [0]
   out = tmp_path / 'j3d.hsaco'
   kernel.compile_to_code_object(text, str(out))
   assert open(out, 'rb').read(4) == b'\x7fELF'

@@ -199,11 +199,13 @@ def test_3d_wave_pipelined_depth_4(app, shape, iterate):
 
 
 @pytest.mark.parametrize('options', [dict(), dict(wp_loader=1, wp_waves_per_eu=3),
-                                     dict(wp_split=1), dict(wp_prefetch=1)])
+                                     dict(wp_split=1), dict(wp_prefetch=1),
+                                     dict(wp_pairs=0), dict(wp_pairs=1, wp_waves_per_eu=3),
+                                     dict(wp_pairs=1, wp_rows=12)])
 def test_3d_wave_pipelined_forms_on_heat3d(options):
   """The depth-4 generator on heat3d (FMA-sensitive expression) in its optional
-  forms: LDS-direct loader wavefront,
-  one row block per wavefront, register prefetch."""
+  forms: packed pair-rows (the default for float programs) and scalar,
+  LDS-direct loader wavefront, one row block per wavefront, register prefetch."""
   from soda_hip.codegen import kernel
   for shape, iterate in (((30, 45, 70), 4), ((24, 64, 131), 9)):
     spec = gpu_util.load_spec('heat3d', iterate=iterate)

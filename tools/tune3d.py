@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Times and checks variants of the 3-D fused kernels on the GPU box.
+usage: tune3d.py app N iterate 'key=value,...' ...   (options of kernel.generate;
+wp_* go to the depth-4 wave-pipelined kernel).  Each variant is first compared
+with the oracle on a small ragged grid, then timed on N^3."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd')]
+import numpy as np
+import torch  # noqa: F401
+from soda_hip import frontend
+from soda_hip.codegen import kernel, spec as specmod
+from soda_hip.runtime import host
+from oracle import soda_oracle
+
+app, n, iterate = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+st = frontend.load(os.path.join(ROOT, 'tests', 'samples', app + '.soda'), iterate=iterate)
+spec = specmod.spec_from_stencil(st)
+rng = np.random.default_rng(1)
+a = rng.random((n, n, n), dtype=np.float32)
+din = host.DeviceArray(a.nbytes); din.upload(a)
+dout = host.DeviceArray(a.nbytes); dout.zero()
+small = rng.random((45, 70, 131), dtype=np.float32)
+orc = soda_oracle.Oracle(spec)
+for variant in sys.argv[4:] or ['']:
+  opts = {k: (int(v) if v.lstrip('-').isdigit() else v)
+          for k, v in (kv.split('=') for kv in variant.split(',') if kv)}
+  text, table = kernel.generate(spec, **opts)
+  try:
+    prog = host.open_program(source=text, spec=spec)
+  except Exception as e:
+    print(variant, 'FAILED', str(e)[:300]); continue
+  bad = []
+  for it in (4, 9):
+    got = prog.run_numpy([small], iterate=it)[0]
+    want = orc.run([small], iterate=it)[spec['outputs'][0]]
+    sl = orc.valid_slices(tuple(reversed(small.shape)), it)
+    bad.append(int((got[sl] != want[sl]).sum()))
+  t = prog.sweep_timed([din.ptr], [dout.ptr], [n, n, n], iterate, warmup=3, repeats=5)
+  print('%-40s bad %s  %9.1f us/sweep  %d launches  dominant %s %.1f us' % (
+      variant or '(default)', bad, t['kernel_us'], t['launches'], t['dominant_name'],
+      t['dominant_us'] / max(1, t['dominant_launches'])), flush=True)
+  prog.close(); prog.blob.unload()
