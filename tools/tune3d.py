@@ -23,7 +23,8 @@ dout = host.DeviceArray(a.nbytes); dout.zero()
 small = rng.random((45, 70, 131), dtype=np.float32)
 orc = soda_oracle.Oracle(spec)
 for variant in sys.argv[4:] or ['']:
-  opts = {k: (int(v) if v.lstrip('-').isdigit() else v)
+  opts = {k: ([int(x) for x in v.split('/')] if '/' in v else
+              int(v) if v.lstrip('-').isdigit() else v)
           for k, v in (kv.split('=') for kv in variant.split(',') if kv)}
   text, table = kernel.generate(spec, **opts)
   try:
@@ -31,7 +32,7 @@ for variant in sys.argv[4:] or ['']:
   except Exception as e:
     print(variant, 'FAILED', str(e)[:300]); continue
   bad = []
-  for it in (4, 9):
+  for it in (4, 9, 13):
     got = prog.run_numpy([small], iterate=it)[0]
     want = orc.run([small], iterate=it)[spec['outputs'][0]]
     sl = orc.valid_slices(tuple(reversed(small.shape)), it)
