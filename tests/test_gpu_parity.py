@@ -543,9 +543,13 @@ def test_denormals_signed_zeros_and_infinities():
   a[41, 300] = np.inf
   assert (np.abs(a[np.isfinite(a)]) < np.finfo(np.float32).tiny).all()
   prog = program('jacobi2d')
-  for it, depth in ((1, 0), (5, 0), (5, 1)):
+  # 16 and 28 iterations: the packed (v_pk_*_f32) depth-16 and depth-12 kernels;
+  # jacobi averages, so the values stay subnormal all the way
+  for it, depth, deepest in ((1, 0, 1), (5, 0, 4), (5, 1, 1), (16, 0, 16), (28, 0, 16)):
     prog.set_max_depth(depth)
-    got = prog.run_numpy([a], iterate=it)[0]
+    got, timing = prog.run_numpy([a], iterate=it, timed=True)
+    got = got[0]
+    assert timing['max_depth'] == deepest
     want = oracle('jacobi2d').run([a], iterate=it)['t0']
     sl = oracle('jacobi2d').valid_slices((shape[1], shape[0]), it)
     assert np.array_equal(np.isnan(got[sl]), np.isnan(want[sl]))
@@ -554,7 +558,33 @@ def test_denormals_signed_zeros_and_infinities():
     assert np.array_equal(got[sl][finite].view(np.uint32),
                           want[sl][finite].view(np.uint32))
     assert (got[sl][finite] != 0).any()
+    tiny = np.abs(got[sl][finite])
+    assert ((tiny > 0) & (tiny < np.finfo(np.float32).tiny)).any()
   prog.set_max_depth(0)
+
+
+@pytest.mark.parametrize('app', ['jacobi3d', 'heat3d'])
+def test_denormals_in_the_packed_3d_kernel(app):
+  """The same corner cases through the depth-4 3-D kernel (packed pair-rows)."""
+  rng = np.random.default_rng(22)
+  shape = (40, 45, 90)
+  a = (rng.random(shape, dtype=np.float32) * np.float32(3e-39)).astype(np.float32)
+  a[rng.random(shape) < 0.05] = np.float32(-0.0)
+  a[10, 20, 30] = np.inf
+  a[20, 21, 50] = -np.inf
+  a[20, 22, 50] = np.inf
+  prog = program(app)
+  got, timing = prog.run_numpy([a], iterate=4, timed=True)
+  assert timing['max_depth'] == 4
+  name = gpu_util.load_spec(app)['outputs'][0]
+  want = oracle(app).run([a], iterate=4)[name]
+  sl = oracle(app).valid_slices(tuple(reversed(shape)), 4)
+  assert np.array_equal(np.isnan(got[0][sl]), np.isnan(want[sl]))
+  finite = ~np.isnan(want[sl])
+  assert np.array_equal(got[0][sl][finite].view(np.uint32),
+                        want[sl][finite].view(np.uint32))
+  tiny = np.abs(got[0][sl][finite])
+  assert ((tiny > 0) & (tiny < np.finfo(np.float32).tiny)).any()
 
 
 def test_grid_beyond_2_to_31_elements():
