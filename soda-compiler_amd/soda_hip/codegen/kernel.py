@@ -290,7 +290,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
         options = {k[3:]: v for k, v in fused_options.items()
                    if k in ('wp_rows', 'wp_groups', 'wp_prefetch', 'wp_vgpr_budget', 'wp_split',
                            'wp_lds_budget', 'wp_waves_per_eu', 'wp_loader', 'wp_sched_fence',
-                           'wp_ring_prefetch', 'wp_pairs')}
+                           'wp_ring_prefetch', 'wp_pairs', 'wp_xcd_remap')}
         options.setdefault('groups', min(depth * len(spec['stages']), 4))
         if options.get('split', 2) == 2 and not options.get('loader') and \
             options.get('rows', 16) % 2 == 0 and kernel_stream2d_wp.packable(spec):

@@ -28,7 +28,8 @@ from .kernel_stream3d import kernel_name
 
 def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
          max_period=12, vgpr_budget=200, lds_budget=64 * 1024, split=2,
-         waves_per_eu=3, loader=0, ring_prefetch=2, sched_fence=1, pairs=0):
+         waves_per_eu=3, loader=0, ring_prefetch=2, sched_fence=1, pairs=0,
+         xcd_remap=0):
   """Returns (text, kernel table entry).
 
   split=2: the wavefront is a 32 x 2 grid of lanes; lane (lx, ly) holds columns
@@ -57,6 +58,11 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   and stores address rows, so the first wavefront spreads each loaded row over
   the halves of R/2 pairs and the last one gathers them again (register moves
   only there); hand-offs keep the pair layout (16 bytes per lane and pair-row).
+
+  xcd_remap=1 (off): workgroups re-dealt so that each XCD (own L2) works on a
+  contiguous run of tiles.  Measured on MI355X: jacobi3d 512^3 -1.5 % per launch,
+  heat3d +6 %, cfg5 (box shrinking to 112^3) +12 % - the runs unbalance the XCDs
+  when a launch has few workgroups.
 
   loader=1 (with split=2, EXPERIMENTAL, off): an extra wavefront does nothing but
   stream input plane tiles into an LDS ring with LDS-direct loads
@@ -516,14 +522,32 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   line('  const int lane = lane_id();')
   line('  const int wave = __builtin_amdgcn_readfirstlane('
        '__builtin_amdgcn_workitem_id_x() >> 6);')
+  if xcd_remap:
+    # workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an
+    # L2): re-deal them so that every XCD works on a contiguous run of tiles (x
+    # fastest, then y, then the z chunk) and neighbouring tiles, which read each
+    # other's halo, share an L2.  Any placement is correct; bijective.
+    line('  const unsigned gx = __builtin_amdgcn_grid_size_x() / %d;'
+         % ((groups + loader) * LANES))
+    line('  const unsigned gy = __builtin_amdgcn_grid_size_y();')
+    line('  const unsigned total = gx * gy * __builtin_amdgcn_grid_size_z();')
+    line('  const unsigned lin = __builtin_amdgcn_workgroup_id_x() + gx * ('
+         '__builtin_amdgcn_workgroup_id_y() + gy * __builtin_amdgcn_workgroup_id_z());')
+    line('  const unsigned xcd = lin & 7u, within = lin >> 3;')
+    line('  const unsigned share = total >> 3, extra = total & 7u;')
+    line('  const unsigned tile_id = xcd * share + (xcd < extra ? xcd : extra) + within;')
+    line('  const unsigned block_x = tile_id % gx, block_y = (tile_id / gx) % gy, '
+         'block_z = tile_id / (gx * gy);')
+  else:
+    line('  const unsigned block_x = __builtin_amdgcn_workgroup_id_x();')
+    line('  const unsigned block_y = __builtin_amdgcn_workgroup_id_y();')
+    line('  const unsigned block_z = __builtin_amdgcn_workgroup_id_z();')
   line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % C)
-  line('  const i64 xs = x_origin + (i64)__builtin_amdgcn_workgroup_id_x() * %d;'
-       % w_out)
+  line('  const i64 xs = x_origin + (i64)block_x * %d;' % w_out)
   line('  if (xs >= a.box_hi[0]) return;')
-  line('  const i64 yb = a.box_lo[1] + (i64)__builtin_amdgcn_workgroup_id_y() * %d'
-       ' - %d;' % (r_out, y_lo))
+  line('  const i64 yb = a.box_lo[1] + (i64)block_y * %d - %d;' % (r_out, y_lo))
   line('  const i64 chunk = a.param[0] > 0 ? a.param[0] : %d;' % chunk_planes)
-  line('  const i64 z0 = a.box_lo[2] + (i64)__builtin_amdgcn_workgroup_id_z() * chunk;')
+  line('  const i64 z0 = a.box_lo[2] + (i64)block_z * chunk;')
   line('  const i64 z1 = z0 + chunk < a.box_hi[2] ? z0 + chunk : a.box_hi[2];')
   if split == 1:
     line('  const i64 x = xs - %d + lane * %d;' % (halo_lo, C))
