@@ -159,6 +159,21 @@ DEV soda_f4 soda_lds_read_f4(const void* p) {
                : "=v"(v) : "v"((unsigned)(unsigned long long)p) : "memory");
   return v;
 }
+// Wide strips: a lane's 8 consecutive floats from LDS as four register pairs
+// {f[c], f[c+4]} (ds_read2_b32 puts its two dwords into one 64-bit pair): the
+// pairs of the packed form without register moves.  Invisible to the compiler
+// like soda_lds_read_f4, for the same reason.
+typedef float soda_pk2 __attribute__((ext_vector_type(2)));
+DEV void soda_lds_read_pairs4(const void* p, soda_pk2& a, soda_pk2& b, soda_pk2& c,
+                              soda_pk2& d) {
+  asm volatile("ds_read2_b32 %%0, %%4 offset1:4\\n\\t"
+               "ds_read2_b32 %%1, %%4 offset0:1 offset1:5\\n\\t"
+               "ds_read2_b32 %%2, %%4 offset0:2 offset1:6\\n\\t"
+               "ds_read2_b32 %%3, %%4 offset0:3 offset1:7\\n\\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+               : "v"((unsigned)(unsigned long long)p) : "memory");
+}
 DEV int lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }

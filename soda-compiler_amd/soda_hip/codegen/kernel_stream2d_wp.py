@@ -160,7 +160,7 @@ def packable(spec):
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
          max_period=12, vgpr_budget=120, skip_fill=1, pairs=0, align='none',
-         ring=0, waves_per_eu=0, dppadd=0, split=None, sync=1):
+         ring=0, waves_per_eu=0, dppadd=0, split=None, sync=1, ringpk=0):
   """Returns (text, kernel table entry).
 
   pairs=2 (needs the ring): ONE strip of 2 x 64 x C columns per wavefront; a
@@ -335,6 +335,12 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
           # row head+u was issued PF rows ago
           line('        __builtin_amdgcn_s_waitcnt(%d);  // vmcnt(%d)'
                % (vmcnt(PF * P), PF * P))
+          if wide and ringpk and C == 4:
+            # the four pairs straight from the LDS read (ds_read2_b32)
+            line('        soda_lds_read_pairs4(&in_ring[%d][0][0] + lane * 8, %s);'
+                 % (u % RS, ', '.join('%s[%d][%d]' % (inst.ident, s, c)
+                                      for c in range(C))))
+            continue
           for h in range(P):
             line('        const %s_lds ring_v%d = __builtin_bit_cast(%s_lds, '
                  'soda_lds_read_f4(&in_ring[%d][%d][0] + lane * %d + %d));'
