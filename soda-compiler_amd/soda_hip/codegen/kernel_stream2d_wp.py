@@ -160,7 +160,7 @@ def packable(spec):
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
          max_period=12, vgpr_budget=120, skip_fill=1, pairs=0, align='none',
-         ring=0, waves_per_eu=0, dppadd=0, split=None, sync=1, ringpk=0):
+         ring=0, waves_per_eu=0, dppadd=0, split=None, sync=1, ringpk=0, fast_store=1):
   """Returns (text, kernel table entry).
 
   pairs=2 (needs the ring): ONE strip of 2 x 64 x C columns per wavefront; a
@@ -427,6 +427,16 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
         if inst.final:
           line('        { const i64 y = head + %d;' % (u - L))
           line('          if (y >= y0 && y < y1) {')
+          # common case, decided once per strip: no lane's vector straddles an
+          # edge of the store range, so a lane stores its whole vector or nothing
+          line('            if (%s) {' % ('!ragged' if fast_store else 'false'))
+          for half in range(P):
+            sel = '[%d]' % half if pairs else ''
+            xv = 'xb' if half else 'x'
+            line('              if (full_%d) { %s v;%s *(%s*)(g_out + y * W + %s) = v; }'
+                 % (half, vec, ''.join(' v[%d] = out_row[%d]%s;' % (c, c, sel)
+                                       for c in range(C)), vec, xv))
+          line('            } else {')
           for half in range(P):
             sel = '[%d]' % half if pairs else ''
             sfx = 'b' if half and not wide else ''
@@ -439,6 +449,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
             line('            else {%s } }' % ''.join(
                 ' if (%s + %d >= st_lo%s && %s + %d < st_hi%s) q[%d] = out_row[%d]%s;'
                 % (xv, c, sfx, xv, c, sfx, c, c, sel) for c in range(C)))
+          line('            }')
           line('          } }')
         if skip:
           line('        }')
@@ -472,6 +483,16 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
                                                            index[out_name]))
   line('  (void)g_in; (void)g_out; (void)st_lo; (void)st_hi; (void)W; (void)H; '
        '(void)xb; (void)in_ring;')
+  parts = []
+  for half in range(P):
+    sfx = 'b' if half and pairs and not wide else ''
+    xv = 'xb' if half else 'x'
+    line('  const bool full_%d = %s >= st_lo%s && %s + %d <= st_hi%s; (void)full_%d;'
+         % (half, xv, sfx, xv, C, sfx, half))
+    parts.append('(!full_%d && %s + %d > st_lo%s && %s < st_hi%s)'
+                 % (half, xv, C, sfx, xv, sfx))
+  line('  const bool ragged = __builtin_amdgcn_ballot_w64(%s) != 0; (void)ragged;'
+       % ' || '.join(parts))
   line('  const i64 steps = (y1 - y0) + %d;' % (L + geo['y_lo']))
   prologue_steps = max(i.first_step for i in everything)
   prologue_steps = -(-prologue_steps // period) * period if skip_fill else 0
