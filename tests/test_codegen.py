@@ -258,8 +258,10 @@ def test_fill_prologue_start_steps():
 
 def test_dpp_combine_only_for_pure_float32_programs():
   off = ['-mllvm', '-amdgpu-dpp-combine=false']
+  # programs the packed kernels cover also get the ILP-first scheduler
+  ilp = ['-mllvm', '-amdgpu-sched-strategy=max-ilp']
   for app in ('jacobi2d', 'jacobi3d', 'seidel2d', 'heat3d'):
-    assert kernel.extra_flags(spec_of(app)) == []
+    assert kernel.extra_flags(spec_of(app)) == ilp
   for app in ('blur', 'sobel2d', 'denoise2d', 'denoise3d'):   # ints / double math
     assert kernel.extra_flags(spec_of(app)) == off
   head = ('kernel: k\nburst width: 512\nunroll factor: 1\niterate: 2\n'
@@ -271,7 +273,7 @@ def test_dpp_combine_only_for_pure_float32_programs():
   assert flags('int32', 'a(0, 0) - a(2, 0) + a(-2, 0)') == off
   assert flags('float', 'a(0, 0) * 0.3 + a(1, 0) * 2.f') == off        # double literal
   assert flags('float', 'a(0, 0) * 1e3 + a(1, 0)') == off
-  assert flags('float', 'a(0, 0) * .5f + a(1, 0) * 2.f + a(0, 1) * 3') == []
+  assert flags('float', 'a(0, 0) * .5f + a(1, 0) * 2.f + a(0, 1) * 3') == ilp
   assert flags('double', 'a(0, 0) * 0.5 + a(1, 0)') == off
   text, _ = kernel.generate(spec_of('sobel2d'))
   assert kernel.flags_from_text(text) == off

@@ -17,10 +17,12 @@ app, n, iterate = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 st = frontend.load(os.path.join(ROOT, 'tests', 'samples', app + '.soda'), iterate=iterate)
 spec = specmod.spec_from_stencil(st)
 rng = np.random.default_rng(1)
-a = rng.random((n, n, n), dtype=np.float32)
-din = host.DeviceArray(a.nbytes); din.upload(a)
+dins = []
+for _ in spec['inputs']:
+  a = rng.random((n, n, n), dtype=np.float32)
+  d = host.DeviceArray(a.nbytes); d.upload(a); dins.append(d)
 dout = host.DeviceArray(a.nbytes); dout.zero()
-small = rng.random((45, 70, 131), dtype=np.float32)
+small = [rng.random((45, 70, 131), dtype=np.float32) for _ in spec['inputs']]
 orc = soda_oracle.Oracle(spec)
 for variant in sys.argv[4:] or ['']:
   opts = {k: ([int(x) for x in v.split('/')] if '/' in v else
@@ -32,12 +34,13 @@ for variant in sys.argv[4:] or ['']:
   except Exception as e:
     print(variant, 'FAILED', str(e)[:300]); continue
   bad = []
-  for it in (4, 9, 13):
-    got = prog.run_numpy([small], iterate=it)[0]
-    want = orc.run([small], iterate=it)[spec['outputs'][0]]
-    sl = orc.valid_slices(tuple(reversed(small.shape)), it)
+  for it in ((4, 9, 13) if len(spec['inputs']) == len(spec['outputs']) else (1,)):
+    got = prog.run_numpy(small, iterate=it)[0]
+    want = orc.run(small, iterate=it)[spec['outputs'][0]]
+    sl = orc.valid_slices(tuple(reversed(small[0].shape)), it)
     bad.append(int((got[sl] != want[sl]).sum()))
-  t = prog.sweep_timed([din.ptr], [dout.ptr], [n, n, n], iterate, warmup=3, repeats=5)
+  t = prog.sweep_timed([d.ptr for d in dins], [dout.ptr], [n, n, n], iterate, warmup=3,
+                       repeats=5)
   print('%-40s bad %s  %9.1f us/sweep  %d launches  dominant %s %.1f us' % (
       variant or '(default)', bad, t['kernel_us'], t['launches'], t['dominant_name'],
       t['dominant_us'] / max(1, t['dominant_launches'])), flush=True)
