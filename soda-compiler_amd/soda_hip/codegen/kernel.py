@@ -202,7 +202,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
           single = kernel_stream2d.emit(
               spec, depth, **common,
               **{k: v for k, v in fused_options.items()
-                 if k not in ('pairs', 'ring', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store')})
+                 if k not in ('pairs', 'ring', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store', 'prio')})
         except kernel_stream2d.NotFusable as e:
           notes.append('depth %d not fused: %s' % (depth, e))
       want_piped = depth >= WAVE_PIPELINE_MIN_DEPTH and (
@@ -212,7 +212,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
       if want_piped:
         options = {k: v for k, v in fused_options.items()
                    if k in ('skip_fill', 'vgpr_budget', 'max_period', 'pairs', 'align',
-                            'ring', 'waves_per_eu', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store')}
+                            'ring', 'waves_per_eu', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store', 'prio')}
         if groups == -1:
           options.setdefault('vgpr_budget', AUTO_WP_BUDGET)
           lane_bytes = common['cols'] * specmod.ELEM_SIZE[spec['inputs'][0]['c_type']]
@@ -259,7 +259,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
               single = kernel_stream2d.emit(
                   spec, depth, **common,
                   **{k: v for k, v in fused_options.items()
-                 if k not in ('pairs', 'ring', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store')})
+                 if k not in ('pairs', 'ring', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store', 'prio')})
             except kernel_stream2d.NotFusable as e2:
               notes.append('depth %d not fused: %s' % (depth, e2))
       if piped is None and single is None:
@@ -299,7 +299,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
         options = {k[3:]: v for k, v in fused_options.items()
                    if k in ('wp_rows', 'wp_groups', 'wp_prefetch', 'wp_vgpr_budget', 'wp_split',
                            'wp_lds_budget', 'wp_waves_per_eu', 'wp_loader', 'wp_sched_fence',
-                           'wp_ring_prefetch', 'wp_pairs', 'wp_xcd_remap')}
+                           'wp_ring_prefetch', 'wp_pairs', 'wp_xcd_remap', 'wp_prio')}
         options.setdefault('groups', min(depth * len(spec['stages']), 4))
         if options.get('split', 2) == 2 and not options.get('loader') and \
             options.get('rows', 16) % 2 == 0 and kernel_stream2d_wp.packable(spec):

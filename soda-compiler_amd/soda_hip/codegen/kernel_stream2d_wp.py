@@ -160,7 +160,7 @@ def packable(spec):
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
          max_period=12, vgpr_budget=120, skip_fill=1, pairs=0, align='none',
-         ring=0, waves_per_eu=0, dppadd=0, split=None, sync=1, ringpk=0, fast_store=1):
+         ring=0, waves_per_eu=0, dppadd=0, split=None, sync=1, ringpk=0, fast_store=1, prio=None):
   """Returns (text, kernel table entry).
 
   pairs=2 (needs the ring): ONE strip of 2 x 64 x C columns per wavefront; a
@@ -498,6 +498,16 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   prologue_steps = -(-prologue_steps // period) * period if skip_fill else 0
   for g, mine in enumerate(per_wave):
     line('  %sif (wave == %d) {' % ('' if g == 0 else 'else ', g))
+    # Issue priority per wavefront ('a/b/c/d'; default: the first one raised).
+    # With equal priorities the four wavefronts of a SIMD (one per workgroup, all
+    # at the same pipeline stage) compete round-robin and stall together; any
+    # inequality staggers them.  Measured per launch on 16384^2: jacobi2d depth
+    # 16 561 -> 550 us (the same for 3/0/0/0, 0/0/0/3, 3/2/1/0; 3/3/3/3 = no
+    # change), seidel2d depth 16 619 -> 605, blur depth 12 606 -> 577.
+    levels = [3] + [0] * (groups - 1) if prio is None else \
+        ([int(v) for v in (prio if isinstance(prio, (list, tuple)) else str(prio).split('/'))] + [0] * groups)[:groups]
+    if levels[g]:
+      line('    __builtin_amdgcn_s_setprio(%d);' % levels[g])
     for inst in mine:
       if inst.keep:
         line('    %s %s[%d][%d];' % ('pk2' if pairs else builtin_type(inst.c_type),

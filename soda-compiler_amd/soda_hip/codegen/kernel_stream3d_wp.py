@@ -29,7 +29,7 @@ from .kernel_stream3d import kernel_name
 def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
          max_period=12, vgpr_budget=200, lds_budget=64 * 1024, split=2,
          waves_per_eu=3, loader=0, ring_prefetch=2, sched_fence=1, pairs=0,
-         xcd_remap=0):
+         xcd_remap=0, prio='3'):
   """Returns (text, kernel table entry).
 
   split=2: the wavefront is a 32 x 2 grid of lanes; lane (lx, ly) holds columns
@@ -493,6 +493,11 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   for g, mine in enumerate(per_wave):
     line('  %sif (wave == %d) {' % ('' if g == 0 and not loader else 'else ',
                                    g + loader))
+    levels = ([int(v) for v in (prio if isinstance(prio, (list, tuple)) else str(prio).split('/'))] + [0] * groups)[:groups]
+    # issue priority per wavefront, as in kernel_stream2d_wp (first one raised:
+    # heat3d 380 -> 374 us per launch, cfg5 6.77 -> 6.67 ms)
+    if levels[g]:
+      line('    __builtin_amdgcn_s_setprio(%d);' % levels[g])
     for inst in mine:
       if inst.keep:
         line('    %s %s[%d][%d][%d];' % ('pk2' if pairs else builtin_type(inst.c_type),
