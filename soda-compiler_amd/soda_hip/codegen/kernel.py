@@ -202,7 +202,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
           single = kernel_stream2d.emit(
               spec, depth, **common,
               **{k: v for k, v in fused_options.items()
-                 if k not in ('pairs', 'ring', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store', 'prio')})
+                 if k not in ('pairs', 'ring', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store', 'prio', 'rotate')})
         except kernel_stream2d.NotFusable as e:
           notes.append('depth %d not fused: %s' % (depth, e))
       want_piped = depth >= WAVE_PIPELINE_MIN_DEPTH and (
@@ -212,7 +212,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
       if want_piped:
         options = {k: v for k, v in fused_options.items()
                    if k in ('skip_fill', 'vgpr_budget', 'max_period', 'pairs', 'align',
-                            'ring', 'waves_per_eu', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store', 'prio')}
+                            'ring', 'waves_per_eu', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store', 'prio', 'rotate')}
         if groups == -1:
           options.setdefault('vgpr_budget', AUTO_WP_BUDGET)
           lane_bytes = common['cols'] * specmod.ELEM_SIZE[spec['inputs'][0]['c_type']]
@@ -259,7 +259,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
               single = kernel_stream2d.emit(
                   spec, depth, **common,
                   **{k: v for k, v in fused_options.items()
-                 if k not in ('pairs', 'ring', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store', 'prio')})
+                 if k not in ('pairs', 'ring', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store', 'prio', 'rotate')})
             except kernel_stream2d.NotFusable as e2:
               notes.append('depth %d not fused: %s' % (depth, e2))
       if piped is None and single is None:

@@ -160,7 +160,7 @@ def packable(spec):
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
          max_period=12, vgpr_budget=120, skip_fill=1, pairs=0, align='none',
-         ring=0, waves_per_eu=0, dppadd=0, split=None, sync=1, ringpk=0, fast_store=1, prio=None):
+         ring=0, waves_per_eu=0, dppadd=0, split=None, sync=1, ringpk=0, fast_store=1, prio=None, rotate=0):
   """Returns (text, kernel table entry).
 
   pairs=2 (needs the ring): ONE strip of 2 x 64 x C columns per wavefront; a
@@ -550,8 +550,14 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   line('  __attribute__((shared)) %s in_ring[%d][%d][%d];' % (
       T_in, RS if RS else 1, ring_dims[0], ring_dims[1]))
   line('  const int lane = lane_id();')
-  line('  const int wave = __builtin_amdgcn_readfirstlane('
-       '__builtin_amdgcn_workitem_id_x() >> 6);')
+  if rotate:   # which wavefront plays which group differs from workgroup to
+    # workgroup (measured: 549 vs 543 us per depth-16 launch - no gain, off)
+    line('  const int wave = (__builtin_amdgcn_readfirstlane('
+         '__builtin_amdgcn_workitem_id_x() >> 6) + (int)__builtin_amdgcn_workgroup_id_x()'
+         ' + (int)__builtin_amdgcn_workgroup_id_y()) %% %d;' % groups)
+  else:
+    line('  const int wave = __builtin_amdgcn_readfirstlane('
+         '__builtin_amdgcn_workitem_id_x() >> 6);')
   line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % geo['origin_align'])
   tile_cols = geo['w_out'] * (1 if wide or not pairs else 2)
   line('  const i64 xs = x_origin + (i64)__builtin_amdgcn_workgroup_id_x() * %d;'
