@@ -55,7 +55,7 @@ DEEP_3D_DEPTHS = (4,)
 # depth-4 launch against 2 x 374 us at depth 2, heat3d (15) 622 us against
 # 2 x 411 us; heavier programs are VALU-bound at depth 2 already
 DEEP_3D_MAX_WEIGHT = 20
-PACKED_3D_SQUEEZE_WEIGHT = 10
+PACKED_3D_LIGHT_WEIGHT = 10
 # ... and only programs that are light on arithmetic (denoise2d, ~70 weighted
 # operations per cell, is VALU-bound at depth 1 and loses 19 % to the narrower
 # aligned strips; blur 20, sobel2d 28, jacobi2d 5 gain)
@@ -98,13 +98,16 @@ def extra_flags(spec):
   add/sub/mul with a DPP operand is verified bit-exact and the fusion is worth
   ~10 % on the jacobi kernels, so float32-only programs keep the pass."""
   tuning = os.environ.get('SODA_HIP_TUNE_FLAGS', '').split()   # experiments only
-  if not tuning and kernel_stream2d_wp.packable(specmod.inline_pointwise(spec)):
+  if not tuning and spec['dim'] == 2 and \
+      kernel_stream2d_wp.packable(specmod.inline_pointwise(spec)):
     # The packed kernels run at a register cap under which the default scheduler
     # serialises whole level-rows on one accumulator pair; the ILP-first strategy
     # keeps the four cells of a row interleaved.  Scheduling only: same results.
     # Measured per launch on 16384^2: jacobi2d depth 16 566 -> 557 us, depth 12
     # 508 -> 505, seidel2d depth 16 620 -> 615, depth 8 506 -> 489; the other
-    # depths and the 3-D kernels within +-0.5 %.
+    # depths within +-0.5 %.  Not for 3-D programs: hipcc then gives the packed
+    # heat3d kernel 276 registers instead of 230 (one workgroup per CU, 647 us
+    # per launch instead of 400).
     tuning = ['-mllvm', '-amdgpu-sched-strategy=max-ilp']
   if dpp_combine_is_safe(spec):
     return tuning
@@ -303,15 +306,18 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
         options.setdefault('groups', min(depth * len(spec['stages']), 4))
         if options.get('split', 2) == 2 and not options.get('loader') and \
             options.get('rows', 16) % 2 == 0 and kernel_stream2d_wp.packable(spec):
-          # packed pair-rows (v_pk_*_f32).  Light programs are bounded by memory
-          # and keep three workgroups per CU (jacobi3d 512^3, per launch: 302 ->
-          # 297 us); heavier ones need the registers (heat3d: 459 us scalar, 629 us
-          # packed at three workgroups per CU with 360 spilled registers, 383 us
-          # packed at the 230 VGPRs the compiler asks for)
-          options.setdefault('pairs', 1)
+          # packed pair-rows (v_pk_*_f32) for programs heavy enough on arithmetic:
+          # heat3d (weight 15) 459 us per launch scalar, 383-440 us packed at the
+          # 230 VGPRs the compiler asks for (629 us capped at three workgroups per
+          # CU: 360 spilled registers).  Light programs are bounded by memory and
+          # keep the scalar form at three workgroups per CU: jacobi3d (weight 7),
+          # cfg5 with the offline compiler: 6.23 ms scalar, 7.43 ms packed (36
+          # spilled registers); hiprtc happens to favour the packed form (6.31 vs
+          # 6.63 ms) - the shipped code objects are built by hipcc.
+          options.setdefault('pairs', int(arithmetic_weight(spec) >
+                                          PACKED_3D_LIGHT_WEIGHT))
           if options['pairs']:
-            options.setdefault('waves_per_eu', 3 if arithmetic_weight(spec) <=
-                               PACKED_3D_SQUEEZE_WEIGHT else 0)
+            options.setdefault('waves_per_eu', 0)
         try:
           ftext, entry = kernel_stream3d_wp.emit(spec, depth, **options)
         except kernel_stream2d.NotFusable as e:

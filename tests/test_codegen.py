@@ -179,10 +179,14 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   assert k4[0]['min_extent'] == [64, 32] and k4[0]['tile'][:2] == [56, 24]
   assert k4[0]['lds_bytes'] <= 64 * 1024
   assert 'v_permlane32_swap' in text or 'rows_across_halves' in text
-  # float program of + - * /: packed pair-rows, seams as scalar pairs
-  assert k4[0]['pairs'] == 1 and 'pk2_shifted{' in text
-  scalar = kernel.generate(spec, wp_pairs=0)[1]
-  assert [k['pairs'] for k in scalar if k['depth'] == 4] == [0]
+  # light on arithmetic (memory-bound): scalar form; heat3d: packed pair-rows,
+  # seams as scalar pairs
+  assert k4[0]['pairs'] == 0
+  packed_text, packed = kernel.generate(spec, wp_pairs=1)
+  assert [k['pairs'] for k in packed if k['depth'] == 4] == [1]
+  assert 'pk2_shifted{' in packed_text
+  heat = kernel.generate(spec_of('heat3d', iterate=8))[1]
+  assert [k['pairs'] for k in heat if k['depth'] == 4] == [1]
   out = tmp_path / 'j3d.hsaco'
   kernel.compile_to_code_object(text, str(out))
   assert open(out, 'rb').read(4) == b'\x7fELF'
@@ -258,10 +262,12 @@ def test_fill_prologue_start_steps():
 
 def test_dpp_combine_only_for_pure_float32_programs():
   off = ['-mllvm', '-amdgpu-dpp-combine=false']
-  # programs the packed kernels cover also get the ILP-first scheduler
+  # 2-D programs the packed kernels cover also get the ILP-first scheduler
   ilp = ['-mllvm', '-amdgpu-sched-strategy=max-ilp']
-  for app in ('jacobi2d', 'jacobi3d', 'seidel2d', 'heat3d'):
+  for app in ('jacobi2d', 'seidel2d'):
     assert kernel.extra_flags(spec_of(app)) == ilp
+  for app in ('jacobi3d', 'heat3d'):
+    assert kernel.extra_flags(spec_of(app)) == []
   for app in ('blur', 'sobel2d', 'denoise2d', 'denoise3d'):   # ints / double math
     assert kernel.extra_flags(spec_of(app)) == off
   head = ('kernel: k\nburst width: 512\nunroll factor: 1\niterate: 2\n'

@@ -564,8 +564,9 @@ def test_denormals_signed_zeros_and_infinities():
 
 
 @pytest.mark.parametrize('app', ['jacobi3d', 'heat3d'])
-def test_denormals_in_the_packed_3d_kernel(app):
-  """The same corner cases through the depth-4 3-D kernel (packed pair-rows)."""
+def test_denormals_in_the_deep_3d_kernel(app):
+  """The same corner cases through the depth-4 3-D kernel (scalar for jacobi3d,
+  packed pair-rows for heat3d)."""
   rng = np.random.default_rng(22)
   shape = (40, 45, 90)
   a = (rng.random(shape, dtype=np.float32) * np.float32(3e-39)).astype(np.float32)

@@ -18,8 +18,13 @@ CASES = [
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 rows = []
 for name, args in CASES:
-  r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1',
-                      '--cpu-seconds', '3'] + args, capture_output=True, text=True)
+  # short steps are repeated until the timed region is ~0.1 s: a burst of a few
+  # milliseconds runs at lower clocks (heat3d x20: 3.3 ms per step in a 3-step
+  # run, 2.2 ms in a 30-step run)
+  steps, warmup = ('3', '1') if 'cfg4' in name else ('30', '10')
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', steps,
+                      '--warmup', warmup, '--cpu-seconds', '3'] + args,
+                     capture_output=True, text=True)
   line = [l for l in r.stdout.splitlines() if l.startswith('{"metric')]
   if not line:
     print(name, 'FAILED', r.stderr[-500:]); continue

@@ -32,7 +32,12 @@ for variant in sys.argv[4:]:
     extra.setdefault('vgpr_budget', 400)
   text, table = kernel.generate(spec, depths=[depth], cols=cols, chunk_rows=chunk, prefetch=pf, **extra)
   try:
-    prog = host.open_program(source=text, spec=spec)
+    if os.environ.get('TUNE_HIPCC'):     # offline compile, as the shipped blobs
+      path = '/tmp/tune_%d.hsaco' % os.getpid()
+      kernel.compile_to_code_object(text, path)
+      prog = host.open_program(blob=path, spec=spec)
+    else:
+      prog = host.open_program(source=text, spec=spec)
   except Exception as e:
     print(variant, 'FAILED', str(e)[:300]); continue
   tc = time.time() - t0

@@ -30,7 +30,12 @@ for variant in sys.argv[4:] or ['']:
           for k, v in (kv.split('=') for kv in variant.split(',') if kv)}
   text, table = kernel.generate(spec, **opts)
   try:
-    prog = host.open_program(source=text, spec=spec)
+    if os.environ.get('TUNE_HIPCC'):     # offline compile, as the shipped blobs
+      path = '/tmp/tune3d_%d.hsaco' % os.getpid()
+      kernel.compile_to_code_object(text, path)
+      prog = host.open_program(blob=path, spec=spec)
+    else:
+      prog = host.open_program(source=text, spec=spec)
   except Exception as e:
     print(variant, 'FAILED', str(e)[:300]); continue
   bad = []
