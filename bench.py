@@ -249,6 +249,9 @@ def run_single(args):
 
 def main():
   args = parse_args()
+  # RCCL between processes needs dmabuf IPC on this driver stack (exported by the
+  # image already; kept for environments built by hand)
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
   world = int(os.environ.get('WORLD_SIZE', '1'))
   if args.gpus > 1 and 'RANK' not in os.environ:
     # started by hand without a launcher: start one rank per GPU as CHILD
