@@ -259,6 +259,31 @@ class Stencil:
                 for i, o in zip(self.input_names, self.output_names)}
     return result
 
+  def overall_windows(self, iterations=None, inputs=None):
+    """{output: sorted tuple of offsets} - the POINT SET of program-input cells
+    an output cell depends on after `iterations` iterations, relative to the
+    store (reference core.py:794-830 get_overall_stencil_window over all
+    inputs).  The bounding box of it is what iteration_boxes tracks; the points
+    themselves decide STENCIL_DISTANCE, the delay of the reference's tiled
+    output layout (core.py:782-785)."""
+    iterations = self.iterate if iterations is None else iterations
+    origin = (0,) * self.dim
+    # `inputs`: only dependences on these program inputs (the reference sizes its
+    # copy-back loops by the FIRST input alone, host.py:832-839)
+    feed = {name: {origin} if inputs is None or name in inputs else set()
+            for name in self.input_names}
+    points = {}
+    for _ in range(iterations):
+      points = dict(feed)
+      for name in self.order:
+        acc = set()
+        for parent, rel in self.stages[name].rel_loads():
+          acc |= {tuple(a + b for a, b in zip(p, rel)) for p in points[parent]}
+        points[name] = acc
+      if len(self.input_names) == len(self.output_names):
+        feed = {i: points[o] for i, o in zip(self.input_names, self.output_names)}
+    return {o: tuple(sorted(points[o])) for o in self.output_names}
+
   def valid_margins(self, iterations=None):
     """[(lo, hi)] per iteration for the program OUTPUTS (hull over outputs):
     after k+1 iterations the outputs are defined on `[lo_d, N_d - hi_d)`."""

@@ -623,3 +623,43 @@ def test_grid_beyond_2_to_31_elements():
     dout.free()
     prog.close()
     _PROGRAMS.pop('jacobi2d', None)
+
+
+@pytest.mark.parametrize('fixture', ['layout.jacobi2d.iter1.40x21.npz',
+                                     'layout.blur.iter1.50x9.npz',
+                                     'layout.jacobi3d.iter2.20x18x6.npz'])
+def test_run_on_data_in_the_reference_dram_layout(fixture):
+  """Buffers the reference's own tiling loops produced (tests/golden/layout.*)
+  go in; what comes out, read back the way the reference's copy-back loops read
+  its device buffers, equals the oracle on every copied-back valid cell."""
+  import json
+  from soda_hip import frontend
+  from soda_hip.codegen import kernel, spec as specmod
+  from soda_hip.runtime import layout
+  golden = os.path.join(gpu_util.ROOT, 'tests', 'golden')
+  with open(os.path.join(golden, 'layout_manifest.json')) as f:
+    meta = json.load(f)[fixture]
+  data = np.load(os.path.join(golden, fixture))
+  st = frontend.load(os.path.join(gpu_util.ROOT, 'tests', 'samples',
+                                  meta['app'] + '.soda'), iterate=meta['iterate'])
+  spec = specmod.spec_from_stencil(st)
+  prog = host.open_program(source=kernel.generate(spec)[0], spec=spec)
+  in_buffers = {n: {b: data['inbuf_%s_%d' % (n, b)] for b in meta['banks_in']}
+                for n in st.input_names}
+  out = layout.run_in_reference_layout(prog, st, in_buffers, meta['dims'],
+                                       meta['tile_size'], meta['banks_in'],
+                                       meta['banks_out'])
+  c = layout.stencil_constants(st, meta['tile_size'])
+  inputs = [data['in_' + n] for n in st.input_names]
+  orc = soda_oracle.Oracle(spec)
+  want = orc.run(inputs, iterate=meta['iterate'])
+  sl = orc.valid_slices(tuple(meta['dims']), meta['iterate'])
+  for name in st.output_names:
+    lay = layout.TiledLayout(meta['dims'], meta['tile_size'], c['stencil_dim'],
+                             meta['burst_width'], want[name].dtype.itemsize * 8,
+                             meta['banks_out'], input_banks=meta['banks_in'])
+    got = lay.unpack(out[name], c['copy_back_offset'], c['stencil_offset'][name],
+                     window_dim=c['copy_back_dim'])
+    assert np.array_equal(got[sl], want[name][sl]) and want[name][sl].size
+  prog.close()
+  prog.blob.unload()
