@@ -274,6 +274,9 @@ def bench_main(args, open_program, make_input, cpu_baseline, launch_updates,
                         updates_per_launch=local_cells * dom_depth,
                         note='per-GPU figure for rank 0 (nominal cells of its '
                              'slab incl. ghosts x depth)'))
+    # rank 0 has timed its dominant kernel meanwhile: leave together
+    torch.cuda.synchronize()
+    dist.barrier()
     program.close()
     return result
   finally:
