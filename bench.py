@@ -51,6 +51,10 @@ def parse_args():
                   help='CPU baseline sample budget (0 = skip)')
   ap.add_argument('--force-dist', action='store_true',
                   help='take the torch.distributed slab path even with 1 rank')
+  ap.add_argument('--overlap', action='store_true',
+                  help='N > 1: exchange on a side stream beside the interior '
+                       'sweep (boundary bands first); default is exchange, then '
+                       'sweep')
   ap.add_argument('--jit', action='store_true',
                   help='compile the kernels with hiprtc instead of loading the '
                        'code object built by __graft_entry__.build()')
@@ -123,49 +127,117 @@ def cpu_baseline(spec, dims, budget_s):
                          logical, t))
 
 
-def measured_traffic(kernel):
-  """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC
-  pass of this same command (profiles/rNN_traffic.json; tools/collect_profiles.py
-  explains the gfx950 correction).  PMC counters cannot be collected from inside
-  the timed process, so the figure comes from that separate run."""
+def measured_traffic(kernel, dims, iterate):
+  """HBM bytes per launch of `kernel` ON THIS GRID from the newest committed
+  rocprofv3 PMC passes (profiles/rNN_traffic.json, written by
+  tools/collect_profiles.py from separate --pmc runs of this same command: PMC
+  counters cannot be collected from inside the timed process).  Entries are
+  keyed by kernel, grid and iteration count; a shape that was not profiled gives
+  None - a figure taken on another grid says nothing about this one."""
   import glob
   files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
   for path in reversed(files):
     with open(path) as f:
       data = json.load(f)
-    if kernel in data:
-      return data[kernel]['hbm_bytes_per_launch'], os.path.basename(path)
+    for entry in data.get('entries', []):
+      if entry['kernel'] == kernel and list(entry['dims']) == list(dims) and \
+          entry['iterate'] == iterate:
+        return entry, os.path.basename(path)
   return None, None
 
 
-def launch_updates(spec, dims, iterate, depths):
-  """Valid cell-updates done by each launch of a depth schedule."""
+def per_iteration_updates(spec, dims, iterate, rows=None):
+  """Valid cell-updates of each iteration; `rows` = (first, last) restricts the
+  count to those rows of the outermost dimension (one rank's own rows)."""
   from soda_hip.codegen import spec as specmod
-  margins = specmod.iteration_margins(spec, iterate)
-  per_iter = []
-  for lo, hi in margins:
+  out = []
+  for lo, hi in specmod.iteration_margins(spec, iterate):
     cells = 1
-    for d in range(spec['dim']):
+    for d in range(spec['dim'] - 1):
       cells *= max(0, dims[d] - lo[d] - hi[d])
-    per_iter.append(cells)
-  out, done = [], 0
-  for k in depths:
-    out.append(sum(per_iter[done:done + k]))
-    done += k
+    first, last = lo[-1], dims[-1] - hi[-1]
+    if rows is not None:
+      first, last = max(first, rows[0]), min(last, rows[1])
+    out.append(cells * max(0, last - first))
   return out
 
 
-def depth_schedule(program, iterate, max_depth):
-  depths = sorted({k['depth'] for k in program.kernels if k['kind'] == 'fused'
-                   and (max_depth <= 0 or k['depth'] <= max_depth)}, reverse=True)
-  if not depths or max_depth < 0:   # per-stage kernels: one iteration per pass
-    return [1] * iterate
-  seq, left = [], iterate
-  while left > 0:
-    k = next(d for d in depths if d <= left)
-    seq.append(k)
-    left -= k
-  return seq
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T f32 lane-operations
+# per second for adds and multiplies (a packed v_pk_*_f32 does two per lane in
+# twice the cycles: the same rate); FMA would double it but the reference's
+# arithmetic is not contracted.
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+
+
+def roofline_block(spec, program, schedule, updates, timing, dims, iterate):
+  """`schedule` = [(kernel entry, modelled us)] as issued, `updates` = valid
+  cell-updates of each iteration of the sweep that `timing` timed.
+
+  The figures: `frac_algorithmic` is SURVEY.md 8(d)'s (algorithmic bytes per
+  update x updates per launch / launch duration / 8 TB/s; > 1 means temporal
+  blocking at work, it is not a bound); `hbm_measured_frac` the PMC bytes of the
+  same kernel on the same grid / duration / 8 TB/s; `valu_frac` the useful f32
+  lane-operations / duration / the chip's 78.6 T/s.  `bound` names the larger of
+  the two physical fractions and `frac`, `achieved`, `peak`, `unit` belong to it."""
+  from soda_hip.codegen import kernel as kernelmod
+  from soda_hip.codegen import spec as specmod
+  abytes = specmod.algorithmic_bytes_per_update(spec)
+  name = timing['dominant_name']
+  per_launch, done = [], 0
+  for entry, _ in schedule:
+    d = max(1, entry['depth'])
+    if entry['name'] == name:
+      per_launch.append(sum(updates[done:done + d]))
+    done += d if entry['kind'] == 'fused' else 0
+  if not per_launch:      # per-stage kernels: one iteration per group of launches
+    per_launch = list(updates)
+  upd = sum(per_launch) / len(per_launch)
+  avg_s = timing['dominant_us'] / max(1, timing['dominant_launches']) * 1e-6
+  alg = upd * abytes / avg_s / 1e9
+  ops = kernelmod.arithmetic_weight(spec)
+  valu = upd * ops / avg_s / 1e12
+  traffic, source = measured_traffic(name, dims, iterate)
+  block = dict(kernel=name, kernel_avg_us=avg_s * 1e6,
+               kernel_launches=timing['dominant_launches'],
+               updates_per_launch=upd, algorithmic_bytes_per_update=abytes,
+               algorithmic_GBps=alg, frac_algorithmic=alg / HBM_PEAK_GBPS,
+               lane_ops_per_update=ops, valu_Tlaneops=valu,
+               valu_frac=valu / VALU_PEAK_TLANEOPS, traffic=None,
+               hbm_measured_frac=None)
+  hbm_frac = None
+  if traffic:
+    block.update(traffic=traffic['hbm_bytes_per_launch'], traffic_source=source,
+                 traffic_commit=traffic.get('commit'),
+                 traffic_read_bytes=traffic['read_bytes_per_launch'],
+                 traffic_write_bytes=traffic['write_bytes_per_launch'],
+                 hbm_measured_GBps=traffic['hbm_bytes_per_launch'] / avg_s / 1e9)
+    hbm_frac = block['hbm_measured_GBps'] / HBM_PEAK_GBPS
+    block['hbm_measured_frac'] = hbm_frac
+  if hbm_frac is None:
+    # no PMC figure for this shape: the kernel cannot move less than one read
+    # and one write of the box per launch
+    depth = max([e['depth'] for e, _ in schedule if e['name'] == name] or [1])
+    hbm_frac = alg / max(1, depth) / HBM_PEAK_GBPS
+    block['hbm_floor_frac'] = hbm_frac
+  if block['valu_frac'] > hbm_frac:
+    block.update(bound='valu', achieved=valu, peak=VALU_PEAK_TLANEOPS,
+                 unit='Tlane-op/s', frac=block['valu_frac'])
+  else:
+    block.update(bound='hbm', achieved=hbm_frac * HBM_PEAK_GBPS, peak=HBM_PEAK_GBPS,
+                 unit='GB/s', frac=hbm_frac)
+  return block
+
+
+def schedule_text(schedule):
+  """'41x24+1x16' from the launch list."""
+  runs = []
+  for entry, _ in schedule:
+    label = str(entry['depth']) if entry['kind'] == 'fused' else entry['name']
+    if runs and runs[-1][0] == label:
+      runs[-1][1] += 1
+    else:
+      runs.append([label, 1])
+  return '+'.join('%dx%s' % (n, label) for label, n in runs)
 
 
 def run_single(args):
@@ -197,17 +269,12 @@ def run_single(args):
   wall = time.perf_counter() - t0
   # the same loop once more under hipEvents, per launch, for the roofline entry
   timing = program.sweep_timed(ip, op, dims, args.iterate, warmup=0, repeats=1)
+  schedule = program.schedule(dims, args.iterate)
   valid = specmod.valid_cells(spec, dims, args.iterate)
   nominal = cells * args.iterate
   ms_per_step = wall / args.steps * 1e3
   value = valid / (wall / args.steps) / 1e9
   abytes = specmod.algorithmic_bytes_per_update(spec)
-  seq = depth_schedule(program, args.iterate, args.max_depth)
-  per_launch = launch_updates(spec, dims, args.iterate, seq)
-  dom_depth = max(seq, key=lambda k: sum(u for d, u in zip(seq, per_launch) if d == k))
-  dom_updates = [u for d, u in zip(seq, per_launch) if d == dom_depth]
-  dom_avg_s = timing['dominant_us'] / max(1, timing['dominant_launches']) * 1e-6
-  achieved = (sum(dom_updates) / len(dom_updates)) * abytes / dom_avg_s / 1e9
   result = dict(
       metric='gcell_updates_per_s', value=value, unit='Gcell-updates/s',
       n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
@@ -220,25 +287,13 @@ def run_single(args):
           args.iterate), app=args.app, dims=dims, iterate=args.iterate,
                   valid_cell_updates=valid, nominal_cell_updates=nominal,
                   nominal_gcell_updates_per_s=nominal / (wall / args.steps) / 1e9,
-                  launches_per_step=timing['launches'], depth_schedule=
-                  '%dx%d' % (seq.count(dom_depth), dom_depth) + ''.join(
-                      '+%d' % k for k in seq if k != dom_depth),
+                  launches_per_step=timing['launches'],
+                  depth_schedule=schedule_text(schedule),
                   effective_GBps=valid * abytes / (wall / args.steps) / 1e9,
                   device=host.device_info(0)['arch']),
-      roofline=dict(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS,
-                    unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
-                    traffic=measured_traffic(timing['dominant_name'])[0],
-                    traffic_source=measured_traffic(timing['dominant_name'])[1],
-                    kernel=timing['dominant_name'],
-                    kernel_avg_us=dom_avg_s * 1e6,
-                    kernel_launches=timing['dominant_launches'],
-                    algorithmic_bytes_per_update=abytes,
-                    updates_per_launch=sum(dom_updates) / len(dom_updates)))
-  # physical HBM rate of the dominant kernel: PMC bytes per launch / its duration
-  traffic = result['roofline']['traffic']
-  if traffic:
-    result['roofline']['hbm_measured_GBps'] = traffic / dom_avg_s / 1e9
-    result['roofline']['hbm_measured_frac'] = traffic / dom_avg_s / 1e9 / HBM_PEAK_GBPS
+      roofline=roofline_block(spec, program, schedule,
+                              per_iteration_updates(spec, dims, args.iterate),
+                              timing, dims, args.iterate))
   for d in din + dout:
     d.free()
   program.close()
@@ -264,8 +319,8 @@ def main():
     sys.exit(subprocess.call(cmd))
   if args.gpus > 1 or world > 1 or args.force_dist:
     from soda_hip.runtime import dist
-    result = dist.bench_main(args, open_program, make_input, cpu_baseline,
-                             launch_updates, depth_schedule, HBM_PEAK_GBPS)
+    result = dist.bench_main(args, open_program, make_input, per_iteration_updates,
+                             roofline_block, schedule_text)
   else:
     result = run_single(args)
   if result is not None:

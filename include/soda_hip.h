@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SODA_HIP_ABI_VERSION 2
+#define SODA_HIP_ABI_VERSION 3
 #define SODA_HIP_MAX_DIMS 4
 #define SODA_HIP_MAX_TENSORS 16 /* inputs + stages of one program */
 #define SODA_HIP_MAX_IO 8
@@ -157,6 +157,12 @@ typedef struct soda_hip_kernel {
                             inside the array rather than guarded) and fewer than
                             2^30 cells per plane (32-bit in-plane offsets); the
                             scheduler skips it otherwise */
+  /* Cost figures of a streaming kernel, from the kernel printer (0 = none): the
+   * scheduler prices every fused depth with them and splits `iterate` into the
+   * cheapest sequence of launches (soda_hip.cpp: step_seconds). */
+  int32_t step_valu;  /* VALU issue cycles ONE workgroup (all its wavefronts
+                         together) spends per streamed row / plane */
+  int32_t step_bytes; /* HBM bytes one workgroup loads + stores per step */
 } soda_hip_kernel;
 
 /* By-value argument of every generated kernel. */
@@ -220,6 +226,18 @@ int soda_hip_sweep_timed(soda_hip_plan* plan, void* const* in, void* const* out,
                          const int64_t dims[SODA_HIP_MAX_DIMS], int iterate,
                          int warmup, int repeats, void* stream,
                          soda_hip_timing* timing);
+
+/* The launch list soda_hip_sweep would issue for these arguments, without
+ * running or allocating anything: kernel_index[i] = index into the plan's kernel
+ * table of launch i (empty boxes are not launched and not listed), est_us[i] =
+ * its modelled duration (0 when the kernel carries no cost figures).  At most
+ * `capacity` entries are written; *n_launches is the full count.  For callers
+ * that report or plan around the schedule (bench.py, the multi-GPU driver). */
+int soda_hip_plan_schedule(soda_hip_plan* plan,
+                           const int64_t dims[SODA_HIP_MAX_DIMS], int iterate,
+                           const int32_t* valid_lo, const int32_t* valid_hi,
+                           int32_t* kernel_index, double* est_us, int capacity,
+                           int* n_launches);
 
 /* Restricts fused kernels to depth <= max_depth (0 = no limit); for tests and
  * tuning. */

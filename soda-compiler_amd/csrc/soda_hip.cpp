@@ -13,6 +13,7 @@
 #include <hip/hiprtc.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -65,6 +66,7 @@ struct soda_hip_plan {
   std::vector<soda_hip_kernel> kernels;
   std::vector<hipFunction_t> funcs;
   std::vector<int> resident_blocks;  // per kernel: workgroups the chip holds at once
+  int cus = 256;                     // compute units of the device the plan lives on
   int max_depth = 0;
   int chunk_rows_override = 0;       // SODA_HIP_CHUNK_ROWS, for tuning
   // shortest chunk the launcher considers: small grids need many short chunks to
@@ -147,7 +149,7 @@ void output_margins(soda_hip_plan* plan, int iterations, int32_t* lo, int32_t* h
 }
 
 int ensure_scratch(soda_hip_plan* plan, const int64_t* dims, bool need_locals,
-                   bool need_pingpong) {
+                   bool need_pingpong, hipStream_t stream) {
   const soda_hip_program& p = plan->prog;
   size_t cells = 1;
   for (int d = 0; d < p.dim; ++d) cells *= (size_t)dims[d];
@@ -164,8 +166,11 @@ int ensure_scratch(soda_hip_plan* plan, const int64_t* dims, bool need_locals,
       plan->scratch_bytes[slot] = 0;
     }
     HIP_TRY(SODA_HIP_ERR_DEVICE_MALLOC, hipMalloc(&plan->scratch[slot], bytes));
-    // unspecified cells must at least be readable, finite-ish garbage: zero
-    HIP_TRY(SODA_HIP_ERR_DEVICE_RUN, hipMemset(plan->scratch[slot], 0, bytes));
+    // unspecified cells must at least be readable, finite-ish garbage: zero.
+    // On the sweep's own stream: a null-stream memset is not ordered before
+    // kernels on a non-blocking stream and could clobber their results.
+    HIP_TRY(SODA_HIP_ERR_DEVICE_RUN,
+            hipMemsetAsync(plan->scratch[slot], 0, bytes, stream));
     plan->scratch_bytes[slot] = bytes;
     return 0;
   };
@@ -188,7 +193,35 @@ struct Launch {
   int kernel;
   soda_hip_args args;
   unsigned grid[3];
+  double est_us;   // modelled duration (0 = the kernel carries no cost figures)
 };
+
+// Cost model of a streaming launch (what the scheduler compares depths with; it
+// never has to be right in absolute terms).  A workgroup walks `steps` rows or
+// planes; with R workgroups resident per CU one step of all of them takes
+//   max( R * step_valu / 4 SIMDs / (clock * issue efficiency),
+//        R * CUs * step_bytes / HBM rate this access pattern reaches ).
+// Constants measured on MI355X with the jacobi2d kernels of every depth
+// (tools/chunk_sweep.py, 16384^2): step_valu carries the arithmetic plus a fixed
+// cost per streamed row (barrier, ring, hand-offs; kernel.py: annotate_cost) and
+// is issued at the ~2.0 GHz the chip holds under that load; the shallow kernels
+// move 4.5-4.7 TB/s.  Modelled vs measured us per step of a full chip: depth 12
+// 0.91 / 0.89, 16 0.96 / 0.98, 20 0.84 / 0.84, 24 0.96 / 0.96.
+const double kModelValuHz = 2.0e9;
+const double kModelHbmBytesPerSec = 4.6e12;
+const double kModelLaunchUs = 2.0;
+
+double step_seconds(const soda_hip_plan* plan, int k, double blocks) {
+  const soda_hip_kernel& desc = plan->kernels[k];
+  if (desc.step_valu <= 0 && desc.step_bytes <= 0) return 0;
+  const double cus = std::max(1, plan->cus);
+  double per_cu = std::max(1, plan->resident_blocks[k]) / cus;
+  // a grid smaller than the chip holds: fewer workgroups share each CU
+  per_cu = std::min(per_cu, std::max(1.0, blocks / cus));
+  const double valu = per_cu * desc.step_valu / 4.0 / kModelValuHz;
+  const double hbm = per_cu * cus * desc.step_bytes / kModelHbmBytesPerSec;
+  return std::max(valu, hbm);
+}
 
 int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
                 Launch* out, bool* empty) {
@@ -196,6 +229,7 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
   const int dim = plan->prog.dim;
   out->kernel = k;
   out->args = args;
+  out->est_us = 0;
   *empty = false;
   // never launch a box that sticks out of the array
   for (int d = 0; d < dim; ++d)
@@ -238,8 +272,15 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
       if (plan->chunk_rows_override > 0) best = plan->chunk_rows_override;
       tile = best;
       out->args.param[0] = best;
+      const double blocks = (double)inner * (double)((extent + best - 1) / best);
+      const double rounds = std::ceil(blocks / (double)resident);
+      out->est_us = kModelLaunchUs + rounds * (double)(best + desc.fill_rows) *
+                                         step_seconds(plan, k, blocks) * 1e6;
     }
-    const int64_t g = (extent + tile - 1) / tile;
+    int64_t g = (extent + tile - 1) / tile;
+    // per-stage kernels stride over rows / planes by the grid size
+    // (kernel_stage.py), so their outer grid dimensions may be clamped
+    if (d > 0 && desc.kind == SODA_HIP_KERNEL_STAGE) g = std::min<int64_t>(g, 65535);
     if (g > (d == 0 ? 2147483647LL : 65535LL))
       return fail(SODA_HIP_ERR_EXTENTS_TOO_LARGE,
                   "grid dimension %d of kernel %s would be %lld", d, desc.name,
@@ -271,16 +312,20 @@ int check_box_inside(const soda_hip_plan* plan, const soda_hip_args& a,
 int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
                    const int64_t* dims, int iterate, const int32_t* valid_lo,
                    const int32_t* valid_hi, std::vector<Launch>* list,
-                   int* max_depth_used) {
+                   int* max_depth_used, hipStream_t stream, bool dry = false) {
   const soda_hip_program& p = plan->prog;
   if (iterate < 1) return fail(SODA_HIP_ERR_CONSTRAINT, "iterate must be >= 1");
   if (iterate > 1 && p.n_inputs != p.n_outputs)
     return fail(SODA_HIP_ERR_CONSTRAINT,
                 "iterate > 1 needs as many outputs as inputs (%d vs %d)",
                 p.n_inputs, p.n_outputs);
-  for (int j = 0; j < p.n_inputs; ++j)
+  // dry: only the launch list is wanted (soda_hip_plan_schedule): no buffers,
+  // no scratch allocation
+  std::vector<void*> none(SODA_HIP_MAX_IO, nullptr);
+  if (dry) in = out = none.data();
+  for (int j = 0; j < p.n_inputs && !dry; ++j)
     if (!in[j]) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "input %d is NULL", j);
-  for (int j = 0; j < p.n_outputs; ++j)
+  for (int j = 0; j < p.n_outputs && !dry; ++j)
     if (!out[j]) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "output %d is NULL", j);
   int32_t vlo[SODA_HIP_MAX_DIMS] = {0, 0, 0, 0}, vhi[SODA_HIP_MAX_DIMS] = {0, 0, 0, 0};
   for (int d = 0; d < p.dim; ++d) {
@@ -292,6 +337,12 @@ int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
   grow_boxes(plan, iterate);
   list->clear();
   *max_depth_used = 0;
+  if ((int)plan->scratch.size() != p.n_outputs + p.n_stages) {
+    // slots exist (as NULL) before anything is allocated: launch lists may be
+    // built without touching memory (soda_hip_plan_schedule)
+    plan->scratch.assign(p.n_outputs + p.n_stages, nullptr);
+    plan->scratch_bytes.assign(p.n_outputs + p.n_stages, 0);
+  }
 
   // fused kernels available?  (single hull box => single-output programs, or
   // outputs that share a window; the printer only emits them when that holds)
@@ -316,19 +367,79 @@ int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
   if (plan->max_depth < 0) fused_ok = false;  // force per-stage kernels
 
   if (fused_ok) {
-    // greedy split of `iterate` into available depths
+    // Split of `iterate` into the available depths: the cheapest one under the
+    // cost model (make_launch prices every depth on the first box it would run
+    // on; boxes shrink slowly, the ranking holds along the sweep), e.g. jacobi2d
+    // x100 = 5 x depth 20 rather than 4 x depth 24 + a memory-bound depth-4 tail.
+    // Kernels without cost figures: greedy, deepest first.
+    auto first_box = [&](int k) {
+      soda_hip_args a;
+      memset(&a, 0, sizeof a);
+      int32_t mlo[SODA_HIP_MAX_DIMS], mhi[SODA_HIP_MAX_DIMS];
+      output_margins(plan, plan->kernels[k].depth, mlo, mhi);
+      for (int d = 0; d < SODA_HIP_MAX_DIMS; ++d) {
+        a.dims[d] = d < p.dim ? dims[d] : 1;
+        a.box_lo[d] = d < p.dim ? vlo[d] + mlo[d] : 0;
+        a.box_hi[d] = d < p.dim ? dims[d] - vhi[d] - mhi[d] : 1;
+      }
+      return a;
+    };
+    std::vector<int> usable;
+    std::vector<double> price;
+    bool priced = true;
+    for (int k : fused) {
+      if (plan->kernels[k].depth > iterate) continue;
+      Launch l;
+      bool empty = false;
+      int rc = make_launch(plan, k, first_box(k), &l, &empty);
+      if (rc) return rc;
+      if (!empty && l.est_us <= 0) priced = false;
+      usable.push_back(k);
+      price.push_back(empty ? kModelLaunchUs : l.est_us);
+    }
+    if (usable.empty()) return fail(SODA_HIP_ERR_INTERNAL, "no fused kernel of depth 1");
     std::vector<int> seq;
-    for (int left = iterate; left > 0;) {
-      int pick = -1;
-      for (int k : fused)
-        if (plan->kernels[k].depth <= left) { pick = k; break; }
-      if (pick < 0) return fail(SODA_HIP_ERR_INTERNAL, "no fused kernel of depth 1");
-      seq.push_back(pick);
-      left -= plan->kernels[pick].depth;
+    if (priced) {
+      std::vector<double> best(iterate + 1, 1e300);
+      std::vector<int> pick(iterate + 1, -1);
+      best[0] = 0;
+      for (int t = 1; t <= iterate; ++t)
+        for (size_t i = 0; i < usable.size(); ++i) {
+          const int d = plan->kernels[usable[i]].depth;
+          // (<: among equal prices the deeper kernel, listed first, wins)
+          if (d <= t && best[t - d] + price[i] < best[t]) {
+            best[t] = best[t - d] + price[i];
+            pick[t] = (int)i;
+          }
+        }
+      for (int t = iterate; t > 0; t -= plan->kernels[usable[pick[t]]].depth) {
+        if (pick[t] < 0) return fail(SODA_HIP_ERR_INTERNAL, "no fused kernel of depth 1");
+        seq.push_back(usable[pick[t]]);
+      }
+      std::sort(seq.begin(), seq.end(), [&](int a, int b) {
+        return plan->kernels[a].depth > plan->kernels[b].depth;
+      });
+    } else {
+      for (int left = iterate; left > 0;) {
+        int pick = -1;
+        for (int k : usable)
+          if (plan->kernels[k].depth <= left) { pick = k; break; }
+        if (pick < 0) return fail(SODA_HIP_ERR_INTERNAL, "no fused kernel of depth 1");
+        seq.push_back(pick);
+        left -= plan->kernels[pick].depth;
+      }
     }
     const int m = (int)seq.size();
-    if (m > 1) {
-      int rc = ensure_scratch(plan, dims, false, true);
+    if (getenv("SODA_HIP_DEBUG")) {
+      fprintf(stderr, "soda_hip: %d iteration(s) =", iterate);
+      for (int k : seq) fprintf(stderr, " %d", plan->kernels[k].depth);
+      fprintf(stderr, "  (%s;", priced ? "cost model" : "greedy");
+      for (size_t i = 0; i < usable.size(); ++i)
+        fprintf(stderr, " k%d %.1f us", plan->kernels[usable[i]].depth, price[i]);
+      fprintf(stderr, ")\n");
+    }
+    if (m > 1 && !dry) {
+      int rc = ensure_scratch(plan, dims, false, true, stream);
       if (rc) return rc;
     }
     int done = 0;
@@ -381,8 +492,8 @@ int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
   for (int s = 0; s < p.n_stages; ++s)
     if (stage_kernel[s] < 0)
       return fail(SODA_HIP_ERR_NO_KERNEL, "blob has no kernel for stage %d", s);
-  {
-    int rc = ensure_scratch(plan, dims, true, iterate > 1);
+  if (!dry) {
+    int rc = ensure_scratch(plan, dims, true, iterate > 1, stream);
     if (rc) return rc;
   }
   std::vector<void*> src(in, in + p.n_inputs);
@@ -703,6 +814,7 @@ int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* progra
                 "wavefronts per CU\n", pl->kernels[k].name, regs, per_cu,
                 waves_per_block);
       pl->resident_blocks.push_back(std::max(1, cus * per_cu));
+      pl->cus = cus;
     }
     const soda_hip_kernel& d = pl->kernels[k];
     if (d.block[0] < 1 || d.block[1] < 1 || d.block[2] < 1 ||
@@ -742,13 +854,32 @@ int soda_hip_plan_set_max_depth(soda_hip_plan* plan, int max_depth) {
   return 0;
 }
 
+int soda_hip_plan_schedule(soda_hip_plan* plan, const int64_t dims[SODA_HIP_MAX_DIMS],
+                           int iterate, const int32_t* valid_lo,
+                           const int32_t* valid_hi, int32_t* kernel_index,
+                           double* est_us, int capacity, int* n_launches) {
+  if (!plan || !dims || !n_launches) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  std::vector<Launch> list;
+  int depth = 0;
+  int rc = build_schedule(plan, nullptr, nullptr, dims, iterate, valid_lo, valid_hi, &list,
+                          &depth, nullptr, true);
+  if (rc) return rc;
+  *n_launches = (int)list.size();
+  for (int i = 0; i < (int)list.size() && i < capacity; ++i) {
+    if (kernel_index) kernel_index[i] = list[i].kernel;
+    if (est_us) est_us[i] = list[i].est_us;
+  }
+  return 0;
+}
+
 int soda_hip_sweep(soda_hip_plan* plan, void* const* in, void* const* out,
                    const int64_t dims[SODA_HIP_MAX_DIMS], int iterate,
                    const int32_t* valid_lo, const int32_t* valid_hi, void* stream) {
   if (!plan || !in || !out || !dims) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
   std::vector<Launch> list;
   int depth = 0;
-  int rc = build_schedule(plan, in, out, dims, iterate, valid_lo, valid_hi, &list, &depth);
+  int rc = build_schedule(plan, in, out, dims, iterate, valid_lo, valid_hi, &list, &depth,
+                          as_stream(stream));
   if (rc) return rc;
   for (const Launch& l : list) {
     rc = launch_one(plan, l, as_stream(stream));
@@ -766,7 +897,7 @@ int soda_hip_sweep_timed(soda_hip_plan* plan, void* const* in, void* const* out,
   hipStream_t s = as_stream(stream);
   std::vector<Launch> list;
   int depth = 0;
-  int rc = build_schedule(plan, in, out, dims, iterate, nullptr, nullptr, &list, &depth);
+  int rc = build_schedule(plan, in, out, dims, iterate, nullptr, nullptr, &list, &depth, s);
   if (rc) return rc;
   for (int w = 0; w < warmup; ++w)
     for (const Launch& l : list)
@@ -840,15 +971,23 @@ int soda_hip_run_buffers(soda_hip_plan* plan, soda_hip_buffer_t* const* inputs,
   if (iterate < 1) return fail(SODA_HIP_ERR_CONSTRAINT, "iterate must be >= 1");
   output_margins(plan, iterate, mlo, mhi);
 
-  // bounds-query mode (host.py:204-252): a buffer with neither host nor device
-  // memory only gets its required shape filled in.  Outputs keep their extents,
-  // inputs need the outputs' extents plus the stencil window minus one.
+  // Bounds-query mode (host.py:204-252): a buffer with neither host nor device
+  // memory only gets the shape it must have written into it, and nothing runs.
+  // As the generated reference code (its halide_rewrite_buffer, host.py:100-113,
+  // sets min / extent / stride of all four dimensions and leaves elem_size
+  // alone): a null OUTPUT keeps its min and extents and gets dense strides; a
+  // null INPUT gets the first output's min and that output's extents plus the
+  // stencil window minus one (the reference takes the window between the FIRST
+  // input and the first output, core.get_stencil_dim; here it is the composed
+  // window of the first output back to all inputs, which is the same for every
+  // program whose inputs share a window and never smaller).
   bool query = false;
   auto is_null = [](const soda_hip_buffer_t* b) { return b->host == nullptr && b->dev == 0; };
   for (int j = 0; j < p.n_outputs; ++j) query |= is_null(outputs[j]);
   for (int j = 0; j < p.n_inputs; ++j) query |= is_null(inputs[j]);
   if (query) {
     const soda_hip_buffer_t* o0 = outputs[0];
+    const Box& window = plan->boxes[iterate - 1][p.output_tensor[0]];
     for (int j = 0; j < p.n_outputs; ++j) {
       soda_hip_buffer_t* b = outputs[j];
       if (!is_null(b)) continue;
@@ -857,7 +996,6 @@ int soda_hip_run_buffers(soda_hip_plan* plan, soda_hip_buffer_t* const* inputs,
         if (d < p.dim) { b->stride[d] = stride; stride *= b->extent[d]; }
         else { b->min[d] = b->extent[d] = b->stride[d] = 0; }
       }
-      b->elem_size = p.elem_size[p.output_tensor[j]];
     }
     for (int j = 0; j < p.n_inputs; ++j) {
       soda_hip_buffer_t* b = inputs[j];
@@ -866,14 +1004,13 @@ int soda_hip_run_buffers(soda_hip_plan* plan, soda_hip_buffer_t* const* inputs,
       for (int d = 0; d < 4; ++d) {
         if (d < p.dim) {
           b->min[d] = o0->min[d];
-          b->extent[d] = o0->extent[d] + mlo[d] + mhi[d];
+          b->extent[d] = o0->extent[d] + window.hi[d] - window.lo[d];
           b->stride[d] = stride;
           stride *= b->extent[d];
         } else {
           b->min[d] = b->extent[d] = b->stride[d] = 0;
         }
       }
-      b->elem_size = p.elem_size[j];
     }
     return 0;
   }
@@ -881,14 +1018,14 @@ int soda_hip_run_buffers(soda_hip_plan* plan, soda_hip_buffer_t* const* inputs,
   // element-size checks (host.py:254-255, :969-982)
   for (int j = 0; j < p.n_outputs; ++j)
     if (outputs[j]->elem_size != p.elem_size[p.output_tensor[j]]) {
-      fprintf(stderr, "Buffer output %d has elem_size %d instead of %d", j,
+      fprintf(stderr, "Buffer output %d has elem_size %d instead of %d\n", j,
               outputs[j]->elem_size, p.elem_size[p.output_tensor[j]]);
       return fail(SODA_HIP_ERR_BAD_ELEM_SIZE, "output %d: elem_size %d, expected %d", j,
                   outputs[j]->elem_size, p.elem_size[p.output_tensor[j]]);
     }
   for (int j = 0; j < p.n_inputs; ++j)
     if (inputs[j]->elem_size != p.elem_size[j]) {
-      fprintf(stderr, "Buffer input %d has elem_size %d instead of %d", j,
+      fprintf(stderr, "Buffer input %d has elem_size %d instead of %d\n", j,
               inputs[j]->elem_size, p.elem_size[j]);
       return fail(SODA_HIP_ERR_BAD_ELEM_SIZE, "input %d: elem_size %d, expected %d", j,
                   inputs[j]->elem_size, p.elem_size[j]);

@@ -38,7 +38,18 @@ AUTO_WP_GROUPS = 4
 AUTO_WP_BUDGET = 200
 AUTO_WP_RING = 6               # LDS ring slots of the packed form (4 rows in flight)
 AUTO_WP_SQUEEZE_VGPRS = 152
-PACKED_DEEP_DEPTH = 16
+# Depths beyond 12 for programs the packed wave-pipelined form covers.  16 runs at
+# four workgroups per CU (128 VGPRs, 12-slot ring); 20 and 24 keep 5 / 6 levels
+# per wavefront and are capped at 168 VGPRs = three workgroups per CU.  Measured
+# per iteration, jacobi2d, same box (tools/chunk_sweep.py; us at 16384^2 / 8192^2 /
+# the 16384 x 2432 slab of an 8-GPU run): depth 16 36.7 / 9.89 / 6.27, depth 20
+# 34.6 / 9.46 / 5.90, depth 24 33.2 / 9.17 / 5.83.  Past 24 the four-wavefront
+# form spills (depth 28: 49.7), 5 or 6 wavefronts per workgroup load the four
+# SIMDs unevenly (depth 20 on 5: 41.7, depth 32 on 6: 47.2) and 7 or 8
+# (depth 28 / 32: 33.9 / 34.0) are no better than depth 24 on four.
+PACKED_DEEP_DEPTHS = (16, 20, 24)
+PACKED_DEEP_DEPTH = PACKED_DEEP_DEPTHS[0]
+PACKED_DEEP_WAVES_PER_EU = 3      # for the depths above 16
 # packable programs: the packed + ring form also replaces the single-wave form
 # from this depth on (jacobi2d 16384^2 per launch: depth 12 570 vs 617 us, depth 8
 # 501 vs 470 us - the single-wave form stays below)
@@ -156,6 +167,47 @@ def fused_depths(spec, max_depth):
   return [1]
 
 
+# What a workgroup of the wave-pipelined forms spends per streamed row besides
+# arithmetic (barrier, ring and hand-off traffic), as VALU-cycle equivalents
+# summed over its wavefronts.  Fitted to jacobi2d at 16384^2, us per step of a full
+# chip: depth 16 0.98 (four workgroups per CU), 20 0.84, 24 0.96 (three per CU)
+# = workgroups per CU x (0.010 us x depth + 0.080 us).
+WP_STEP_FIXED_CYCLES = 640
+
+
+def annotate_cost(entry, spec):
+  """Cost figures of a streaming kernel for the run-time scheduler
+  (soda_hip_kernel.step_valu / step_bytes, include/soda_hip.h): VALU issue
+  cycles and HBM bytes of ONE workgroup per streamed row or plane.  A wave64
+  instruction on `n` lane-operations' worth of cells costs 2 cycles per cell it
+  covers per lane (a packed instruction covers two cells in 4 cycles: the same)."""
+  elem = specmod.ELEM_SIZE[spec['inputs'][0]['c_type']]
+  weight = max(1, arithmetic_weight(spec))
+  waves = entry['block'][0] // kernel_stream2d.LANES
+  n_in, n_out = len(spec['inputs']), len(spec['outputs'])
+  if spec['dim'] == 2 and 'groups' in entry:      # wave-pipelined: one strip(-pair)
+    lane_cells = entry['cols'] * (2 if entry.get('pairs') else 1)
+    valu = entry['depth'] * weight * lane_cells * 2 + WP_STEP_FIXED_CYCLES
+    cells_in, cells_out = kernel_stream2d.LANES * lane_cells, entry['tile'][0]
+  elif spec['dim'] == 2:                          # one strip per wavefront
+    valu = waves * entry['depth'] * weight * entry['cols'] * 2
+    cells_in = waves * kernel_stream2d.LANES * entry['cols']
+    cells_out = entry['tile'][0]
+  elif 'groups' in entry:                         # 3-D, one level per wavefront
+    lane_cells = entry['rows'] * entry['cols']
+    valu = entry['depth'] * weight * lane_cells * 2 + WP_STEP_FIXED_CYCLES
+    cells_in = kernel_stream2d.LANES * lane_cells
+    cells_out = entry['tile'][0] * entry['tile'][1]
+  else:                                           # 3-D, one tile per wavefront
+    lane_cells = entry['rows'] * entry['cols']
+    valu = waves * entry['depth'] * weight * lane_cells * 2
+    cells_in = waves * kernel_stream2d.LANES * lane_cells
+    cells_out = entry['tile'][0] * entry['tile'][1]
+  entry['step_valu'] = int(valu)
+  entry['step_bytes'] = int((n_in * cells_in + n_out * cells_out) * elem)
+  return entry
+
+
 def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
              fused=True, depths=None, inline=True, wave_groups=None,
              **fused_options):
@@ -183,11 +235,10 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
     # the only one that gains from it (jacobi2d 16384^2: depth 12 single-wave
     # 46.0 us per iteration, depth 16 packed + ring 39.5)
     if (len(wanted) > 1 and max_depth >= DEFAULT_MAX_DEPTH and
-        spec['iterate'] >= PACKED_DEEP_DEPTH and
         len(spec['inputs']) == len(spec['outputs']) == 1 and
         (WAVE_GROUPS if wave_groups is None else wave_groups) == -1 and
         kernel_stream2d_wp.packable(spec)):
-      wanted.append(PACKED_DEEP_DEPTH)
+      wanted += [d for d in PACKED_DEEP_DEPTHS if spec['iterate'] >= d]
     if depths is not None:
       wanted = sorted(set([1] + [d for d in depths if len(wanted) > 1 or d == 1]))
     for depth in wanted:
@@ -231,6 +282,11 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
           # pairs=1: lane-crossing operands as scalar DPP adds (22 instead of 24
           # VALU instructions per jacobi2d level-row: depth 16 627 -> 610 us)
           options.setdefault('dppadd', int(options['pairs'] == 1))
+          if depth > PACKED_DEEP_DEPTH and options['pairs'] == 2:
+            # 5-6 levels per wavefront: three workgroups per CU (168 VGPRs;
+            # depth 24 left alone takes 174 = two per CU: 34.1 vs 33.2 us per
+            # iteration at 16384^2)
+            options.setdefault('waves_per_eu', PACKED_DEEP_WAVES_PER_EU)
         try:
           piped = kernel_stream2d_wp.emit(
               spec, depth, groups=AUTO_WP_GROUPS if groups == -1 else groups,
@@ -269,7 +325,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
         continue
       ftext, entry = piped if piped is not None else single
       parts.append(ftext)
-      table.append(entry)
+      table.append(annotate_cost(entry, spec))
   if fused and spec['dim'] == 3:
     wanted3 = [d for d in (1, 2) if d <= max(1, spec['iterate'])] \
         if len(spec['inputs']) == len(spec['outputs']) == 1 else [1]
@@ -288,7 +344,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
           error = e
           continue
         parts.append(ftext)
-        table.append(entry)
+        table.append(annotate_cost(entry, spec))
         error = None
         break
       if error is not None:
@@ -324,7 +380,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
           notes.append('depth %d not wave-pipelined: %s' % (depth, e))
           continue
         parts.append(ftext)
-        table.append(entry)
+        table.append(annotate_cost(entry, spec))
   if notes:
     parts.append(''.join('// %s\n' % n for n in notes))
   parts.append(kernel_common.meta_symbol(

@@ -49,18 +49,27 @@ def emit(spec):
     rows = {}
     for tensor, rel in stage['loads']:
       key = (tensor, tuple(rel[1:]))
-      lo, hi = rows.get(key, (rel[0], rel[0]))
+      # the row always covers dx = 0: the V-wide centre load lands in
+      # r[-lo .. -lo+V), so a one-sided window (all dx > 0 or all < 0) must not
+      # shrink the register row below it
+      lo, hi = rows.get(key, (min(rel[0], 0), max(rel[0], 0)))
       rows[key] = (min(lo, rel[0]), max(hi, rel[0]))
     lines = ['// stage `%s`: %d cells per work-item along dimension 0'
              % (stage['name'], V),
              'GLOBAL WG_SIZE(%d) void %s(soda_hip_args a) {' % (BLOCK, name),
              '  const i64 x = a.box_lo[0] + ((i64)__builtin_amdgcn_workgroup_id_x()'
              ' * %d + __builtin_amdgcn_workitem_id_x()) * %d;' % (BLOCK, V)]
-    if dim >= 2:
-      lines.append('  const i64 y = a.box_lo[1] + __builtin_amdgcn_workgroup_id_y();')
-    if dim >= 3:
-      lines.append('  const i64 z = a.box_lo[2] + __builtin_amdgcn_workgroup_id_z();')
     lines.append('  if (x >= a.box_hi[0]) return;')
+    # rows / planes: one per workgroup, strided by the grid so that extents
+    # beyond the 65535-workgroup limit of grid.y / grid.z still run (the
+    # launcher clamps the grid there)
+    if dim >= 3:
+      lines.append('  for (i64 z = a.box_lo[2] + __builtin_amdgcn_workgroup_id_z(); '
+                   'z < a.box_hi[2]; z += __builtin_amdgcn_grid_size_z())')
+    if dim >= 2:
+      lines.append('  for (i64 y = a.box_lo[1] + __builtin_amdgcn_workgroup_id_y(); '
+                   'y < a.box_hi[1]; y += __builtin_amdgcn_grid_size_y())')
+    lines.append('  {')
     if dim >= 2:
       lines.append('  const i64 s1 = a.dims[0];')
     if dim >= 3:
@@ -152,6 +161,7 @@ def emit(spec):
       lines.append('  }')
     else:
       lines.append('  t_out[c] = result[0];')
+    lines.append('  }')
     lines.append('}')
     out.append('\n'.join(lines))
     table.append(dict(name=name, kind='stage', depth=0, stage=index[stage['name']],

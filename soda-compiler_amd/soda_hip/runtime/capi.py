@@ -11,7 +11,7 @@ MAX_TENSORS = 16
 MAX_IO = 8
 MAX_WINDOWS = 64
 MAX_KERNELS = 32
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 KERNEL_STAGE = 0
 KERNEL_FUSED = 1
@@ -42,7 +42,8 @@ class KernelDesc(ctypes.Structure):
               ('depth', ctypes.c_int32), ('stage', ctypes.c_int32),
               ('block', ctypes.c_int32 * 3), ('tile', ctypes.c_int32 * MAX_DIMS),
               ('fill_rows', ctypes.c_int32), ('origin_align', ctypes.c_int32),
-              ('min_extent', ctypes.c_int32 * 2)]
+              ('min_extent', ctypes.c_int32 * 2),
+              ('step_valu', ctypes.c_int32), ('step_bytes', ctypes.c_int32)]
 
 
 class Timing(ctypes.Structure):
@@ -99,6 +100,10 @@ SIGNATURES = {
                                             ctypes.c_int, _VPP]),
     'soda_hip_plan_destroy': (ctypes.c_int, [_VP]),
     'soda_hip_plan_margins': (ctypes.c_int, [_VP, ctypes.c_int, _I32P, _I32P]),
+    'soda_hip_plan_schedule': (ctypes.c_int, [_VP, _I64P, ctypes.c_int, _I32P, _I32P,
+                                              _I32P, ctypes.POINTER(ctypes.c_double),
+                                              ctypes.c_int,
+                                              ctypes.POINTER(ctypes.c_int)]),
     'soda_hip_plan_set_max_depth': (ctypes.c_int, [_VP, ctypes.c_int]),
     'soda_hip_sweep': (ctypes.c_int, [_VP, _VPP, _VPP, _I64P, ctypes.c_int, _I32P,
                                       _I32P, _VP]),

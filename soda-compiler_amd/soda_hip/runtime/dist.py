@@ -54,6 +54,12 @@ class SlabPlan:
     self.has_hi = rank < world - 1
     smallest = min(b - a for a, b in bounds)
     reach = max(r_lo, r_hi, 1)
+    if world > 1 and smallest < reach:
+      # a ghost region of even ONE iteration would be deeper than a neighbour's
+      # own rows: the exchange would ship rows the neighbour does not own
+      raise ValueError(
+          'cannot cut %d rows into %d slabs: the smallest slab (%d rows) is '
+          'thinner than the stencil reach (%d)' % (dims[-1], world, smallest, reach))
     # a ghost region cannot be deeper than the neighbour's own rows
     self.exchange = max(1, min(exchange, smallest // reach)) if world > 1 else exchange
     self.ghost_lo = self.exchange * r_lo if self.has_lo else 0
@@ -102,44 +108,114 @@ def exchange_ghosts(array, plan, dist, backend_ops=None):
       req.wait()
 
 
+class SerialSchedule:
+  """How run_slab orders the exchange against the sweeps: here, not at all (the
+  CPU engines of the gloo tests, and the reference point on GPUs)."""
+  overlapped = False
+
+  def before_super_step(self):
+    pass
+
+  def exchange(self, fn):
+    fn()
+
+  def after_bands(self):
+    pass
+
+
+def band_plan(plan, step):
+  """Row ranges (local indices, outermost dimension) of one super-step of `step`
+  iterations cut into the two bands the neighbours are waiting for and the rest:
+  [(r0, r1, cut_lo, cut_hi)] = sweep the sub-array of rows [r0, r1) whose lower /
+  upper side is cut inside valid data (margin 0 there; an uncut side is the
+  slab's own side and keeps the margin the caller computed).  The output rows of
+  the pieces tile the slab's own rows exactly; every piece reads only rows that
+  are valid before the super-step (own rows and freshly exchanged ghost rows)."""
+  first_own, last_own = plan.ghost_lo, plan.ghost_lo + plan.own
+  reach_lo, reach_hi = step * plan.r_lo, step * plan.r_hi
+  bands, lo_edge, hi_edge = [], first_own, last_own
+  if plan.has_lo:      # the lower neighbour's ghost rows: our first send_down rows
+    bands.append((first_own - reach_lo, first_own + plan.send_down + reach_hi,
+                  True, True))
+    lo_edge = first_own + plan.send_down
+  if plan.has_hi:
+    bands.append((last_own - plan.send_up - reach_lo, last_own + reach_hi, True, True))
+    hi_edge = last_own - plan.send_up
+  interior = (lo_edge - reach_lo if plan.has_lo else 0,
+              hi_edge + reach_hi if plan.has_hi else plan.local_extent,
+              plan.has_lo, plan.has_hi)
+  return bands, interior
+
+
 def run_slab(engine, plan, arrays, iterate, margins_of, dist, depth_multiple=1,
-             ghosts_ready=False):
+             ghosts_ready=False, schedule=None):
   """Advances the slab `iterate` iterations.  `arrays` = [A, B, C]: A holds the
   level-0 slab (own rows filled, ghost rows anything) and is not written; the
   result ends up in the returned array (B or C).  Returns (array, exchanges).
 
   ghosts_ready: A's ghost rows already hold the neighbours' level-0 rows (the
   input was distributed with its halo, or an earlier call exchanged them - A is
-  never written, so they stay), and the first exchange is skipped."""
+  never written, so they stay), and the first exchange is skipped.
+
+  schedule: SerialSchedule (default) exchanges, then sweeps the whole slab.  An
+  overlapping schedule (StreamSchedule on GPUs) makes every super-step but the
+  last produce the rows its neighbours need FIRST, as two thin band sweeps, hands
+  them to the exchange of the next super-step on a side stream, and sweeps the
+  interior meanwhile."""
   a, b, c = arrays
+  schedule = schedule or SerialSchedule()
   src, done, exchanges = a, 0, 0
   dst_cycle = [b, c]
   k = 0
+  pending = ghosts_ready      # src's ghost rows are (being) filled already
   while done < iterate:
-    if done or not ghosts_ready:
-      exchange_ghosts(src, plan, dist)
+    if not pending:
+      schedule.exchange(lambda src=src: exchange_ghosts(src, plan, dist))
       exchanges += 1
+    schedule.before_super_step()       # ghost rows of src have landed
+    pending = False
     step = min(plan.exchange, iterate - done)
     lo, hi = plan.valid_margins(done, margins_of)
     dst = dst_cycle[k % 2]
-    engine.sweep(src, dst, plan.local_dims, step, lo, hi)
+    more = done + step < iterate
+    small = plan.own < 2 * (plan.send_down + plan.send_up) + 1
+    if schedule.overlapped and more and plan.world > 1 and not small:
+      bands, interior = band_plan(plan, step)
+
+      def piece(r0, r1, cut_lo, cut_hi):
+        plo, phi = list(lo), list(hi)
+        if cut_lo:
+          plo[-1] = 0
+        if cut_hi:
+          phi[-1] = 0
+        engine.sweep(src, dst, plan.local_dims, step, plo, phi, rows=(r0, r1))
+      for band in bands:
+        piece(*band)
+      schedule.after_bands()
+      schedule.exchange(lambda dst=dst: exchange_ghosts(dst, plan, dist))
+      exchanges += 1
+      pending = True
+      piece(*interior)
+    else:
+      engine.sweep(src, dst, plan.local_dims, step, lo, hi)
     src = dst
     done += step
     k += 1
+  schedule.before_super_step()
   return src, exchanges
 
 
 def auto_exchange(own_rows, reach, deepest, iterate):
   """Iterations between exchanges: a multiple of the deepest fused kernel, up to
-  twelve of them, but never more ghost rows than ~15 % of the slab.
+  eight of them, but never more ghost rows than ~15 % of the slab.
 
-  Measured on one MI355X at the slab sizes of 8 and 4 ranks of the 16384^2
-  jacobi2d grid (own rows + 2 E ghost rows, E iterations): 2048 own rows cost
-  9.07 / 8.24 / 8.09 us per iteration at E = 48 / 96 / 144, 4096 own rows 15.97 /
-  14.30 at E = 48 / 96 - the extra ghost rows are cheaper than they look because
-  taller slabs run the fused kernels more efficiently (longer y-chunks, smaller
-  share of pipeline fill), and every exchange avoided saves its latency."""
-  e = deepest * 12
+  Measured on one MI355X at the slab sizes of 1/2/4/8 ranks of the 16384^2
+  jacobi2d grid (tools/slab_cost.py: own rows + 2 E ghost rows, E iterations,
+  depths up to 24): the cost per iteration hardly depends on E (8 ranks: 5.24 /
+  5.41 / 5.42 / 5.56 us at E = 48 / 96 / 144 / 192; 4 ranks 9.11 / 9.73 / 9.65 /
+  9.60), so E is chosen for the exchange: the ghost BYTES per iteration are fixed,
+  the number of (latency-bound) exchanges is not."""
+  e = deepest * 8
   while e > deepest and e * reach * 2 > max(1, own_rows) * 0.15:
     e -= deepest
   return max(1, min(e, iterate))
@@ -155,14 +231,85 @@ class HipEngine:
   def __init__(self, program, torch):
     self.program, self.torch = program, torch
 
-  def sweep(self, src, dst, local_dims, iterations, valid_lo, valid_hi):
+  def sweep(self, src, dst, local_dims, iterations, valid_lo, valid_hi, rows=None):
+    """rows = (r0, r1): sweep only the sub-array of those rows of the outermost
+    dimension (a contiguous piece of memory: the same call on offset pointers)."""
     stream = self.torch.cuda.current_stream().cuda_stream
-    self.program.sweep([src.data_ptr()], [dst.data_ptr()], local_dims, iterations,
-                       valid_lo, valid_hi, stream=stream)
+    dims = list(local_dims)
+    sp, dp = src.data_ptr(), dst.data_ptr()
+    if rows is not None:
+      row_bytes = src.element_size()
+      for n in dims[:-1]:
+        row_bytes *= n
+      sp, dp = sp + rows[0] * row_bytes, dp + rows[0] * row_bytes
+      dims[-1] = rows[1] - rows[0]
+    self.program.sweep([sp], [dp], dims, iterations, valid_lo, valid_hi,
+                       stream=stream)
 
 
-def bench_main(args, open_program, make_input, cpu_baseline, launch_updates,
-               depth_schedule, hbm_peak):
+class StreamSchedule:
+  """Exchange on a side stream: it starts when the band sweeps have finished
+  (event) and the next super-step waits for it (event), so it runs beside the
+  interior sweep.  RCCL work issued under torch.cuda.stream(side) is ordered
+  after that stream's earlier work, and req.wait() makes the side stream (not
+  the host) wait for it."""
+  overlapped = True
+
+  def __init__(self, torch):
+    self.torch = torch
+    self.side = torch.cuda.Stream()
+    self.bands_done = torch.cuda.Event()
+    self.ghosts_landed = None
+    self.spans = []                     # (start, end) events of every exchange
+
+  def after_bands(self):
+    self.bands_done.record(self.torch.cuda.current_stream())
+    self.side.wait_event(self.bands_done)
+
+  def exchange(self, fn):
+    main = self.torch.cuda.current_stream()
+    if self.ghosts_landed is None and not self.spans:
+      self.side.wait_stream(main)       # the first exchange follows the input
+    t0 = self.torch.cuda.Event(enable_timing=True)
+    t1 = self.torch.cuda.Event(enable_timing=True)
+    with self.torch.cuda.stream(self.side):
+      t0.record()
+      fn()
+      t1.record()
+    self.spans.append((t0, t1))
+    self.ghosts_landed = t1
+
+  def before_super_step(self):
+    if self.ghosts_landed is not None:
+      self.torch.cuda.current_stream().wait_event(self.ghosts_landed)
+      self.ghosts_landed = None
+
+  def exchange_ms(self):
+    total = sum(a.elapsed_time(b) for a, b in self.spans)
+    self.spans = []
+    return total
+
+
+class TimedSerialSchedule(SerialSchedule):
+  """The serial order on a GPU, with the exchanges bracketed by events."""
+
+  def __init__(self, torch):
+    self.torch = torch
+    self.spans = []
+
+  def exchange(self, fn):
+    t0 = self.torch.cuda.Event(enable_timing=True)
+    t1 = self.torch.cuda.Event(enable_timing=True)
+    t0.record()
+    fn()
+    t1.record()
+    self.spans.append((t0, t1))
+
+  exchange_ms = StreamSchedule.exchange_ms
+
+
+def bench_main(args, open_program, make_input, per_iteration_updates,
+               roofline_block, schedule_text):
   """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`."""
   import torch
   import torch.distributed as dist
@@ -209,17 +356,19 @@ def bench_main(args, open_program, make_input, cpu_baseline, launch_updates,
         return (0,) * spec['dim'], (0,) * spec['dim']
       return margin_table[k - 1]
 
-    # the input is resident WITH its halo when the timed region starts: a rank's
-    # level-0 ghost rows are part of its share of the input (A is never written)
-    exchange_ghosts(a, plan, dist)
+    overlap = bool(getattr(args, 'overlap', False)) and world > 1
+    order = StreamSchedule(torch) if overlap else TimedSerialSchedule(torch)
 
+    # Every exchange is inside the timed region, the level-0 one included: a step
+    # starts from own rows only, as a fresh input would arrive.
     def step():
       return run_slab(engine, plan, [a, b, c], args.iterate, margins_of, dist,
-                      ghosts_ready=True)
+                      schedule=order)
 
     for _ in range(args.warmup):
       step()
     torch.cuda.synchronize()
+    order.exchange_ms()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -232,22 +381,22 @@ def bench_main(args, open_program, make_input, cpu_baseline, launch_updates,
                            device=dev)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     wall = float(elapsed.item())
+    exchange_ms = order.exchange_ms() / max(1, args.steps)
     result = None
     if rank == 0:
       valid = specmod.valid_cells(spec, dims, args.iterate)
       nominal = int(np.prod(dims)) * args.iterate
       per_step = wall / args.steps
       abytes = specmod.algorithmic_bytes_per_update(spec)
-      # dominant kernel of THIS rank, timed per launch on its stream
-      seq = depth_schedule(program, min(plan.exchange, args.iterate), args.max_depth)
+      # dominant kernel of THIS rank: its first super-step timed per launch on
+      # this stream, priced on the valid updates of its OWN rows (the same
+      # definition as at N = 1: ghost rows are redundant work and earn nothing)
+      first = min(plan.exchange, args.iterate)
       lo, hi = plan.valid_margins(0, margins_of)
       timing = program.sweep_timed([a.data_ptr()], [b.data_ptr()], plan.local_dims,
-                                   min(plan.exchange, args.iterate), warmup=1,
-                                   repeats=3)
-      dom_avg_s = timing['dominant_us'] / max(1, timing['dominant_launches']) * 1e-6
-      dom_depth = max(seq)
-      local_cells = int(np.prod(plan.local_dims))
-      achieved = local_cells * dom_depth * abytes / dom_avg_s / 1e9
+                                   first, warmup=1, repeats=3)
+      sched = program.schedule(plan.local_dims, first)
+      updates = per_iteration_updates(spec, dims, first, rows=(plan.start, plan.stop))
       result = dict(
           metric='gcell_updates_per_s', value=valid / per_step / 1e9,
           unit='Gcell-updates/s', n_gpus=world, steps=args.steps,
@@ -260,20 +409,20 @@ def bench_main(args, open_program, make_input, cpu_baseline, launch_updates,
                       app=args.app, dims=dims, iterate=args.iterate,
                       parallelism='outer-dim slabs x%d' % world,
                       exchange_every=plan.exchange, exchanges_per_step=exchanges,
+                      exchange_ms_per_step=exchange_ms,
+                      exchange_overlapped=overlap,
                       ghost_rows=[plan.exchange * r_lo, plan.exchange * r_hi],
+                      super_step_schedule=schedule_text(sched),
                       valid_cell_updates=valid, nominal_cell_updates=nominal,
                       nominal_gcell_updates_per_s=nominal / per_step / 1e9,
                       effective_GBps=valid * abytes / per_step / 1e9,
                       device=host.device_info(local_rank)['arch']),
-          roofline=dict(bound='hbm', achieved=achieved, peak=hbm_peak, unit='GB/s',
-                        frac=achieved / hbm_peak, traffic=None,
-                        kernel=timing['dominant_name'],
-                        kernel_avg_us=dom_avg_s * 1e6,
-                        kernel_launches=timing['dominant_launches'],
-                        algorithmic_bytes_per_update=abytes,
-                        updates_per_launch=local_cells * dom_depth,
-                        note='per-GPU figure for rank 0 (nominal cells of its '
-                             'slab incl. ghosts x depth)'))
+          roofline=roofline_block(spec, program, sched, updates, timing,
+                                  plan.local_dims, first))
+      result['roofline']['note'] = (
+          'rank 0, first super-step of %d iterations on its %d own rows + %d ghost '
+          'rows; updates counted on own rows only' % (
+              first, plan.own, plan.ghost_lo + plan.ghost_hi))
     # rank 0 has timed its dominant kernel meanwhile: leave together
     torch.cuda.synchronize()
     dist.barrier()

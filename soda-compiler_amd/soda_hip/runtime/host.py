@@ -184,6 +184,8 @@ def kernel_descs(table):
     d.origin_align = k.get('origin_align', 0)
     for i, v in enumerate(k.get('min_extent', [0, 0])):
       d.min_extent[i] = v
+    d.step_valu = int(k.get('step_valu', 0))
+    d.step_bytes = int(k.get('step_bytes', 0))
   return arr
 
 
@@ -255,6 +257,24 @@ class Program:
     capi.check(capi.lib().soda_hip_sweep(
         self.handle, self._ptr_array(in_ptrs), self._ptr_array(out_ptrs),
         self._dims(dims), iterate, vlo, vhi, stream))
+
+  def schedule(self, dims, iterate, valid_lo=None, valid_hi=None):
+    """The launches `sweep` would issue: [(kernel table entry, modelled us)]."""
+    vlo = vhi = None
+    if valid_lo is not None:
+      vlo = (ctypes.c_int32 * 4)(*(list(valid_lo) + [0] * (4 - len(valid_lo))))
+    if valid_hi is not None:
+      vhi = (ctypes.c_int32 * 4)(*(list(valid_hi) + [0] * (4 - len(valid_hi))))
+    n = ctypes.c_int()
+    capi.check(capi.lib().soda_hip_plan_schedule(
+        self.handle, self._dims(dims), iterate, vlo, vhi, None, None, 0,
+        ctypes.byref(n)))
+    idx = (ctypes.c_int32 * max(1, n.value))()
+    est = (ctypes.c_double * max(1, n.value))()
+    capi.check(capi.lib().soda_hip_plan_schedule(
+        self.handle, self._dims(dims), iterate, vlo, vhi, idx, est, n.value,
+        ctypes.byref(n)))
+    return [(self.kernels[idx[i]], est[i]) for i in range(n.value)]
 
   def sweep_timed(self, in_ptrs, out_ptrs, dims, iterate, warmup=1, repeats=1,
                   stream=None):

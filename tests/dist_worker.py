@@ -26,10 +26,13 @@ class OracleEngine:
     self.spec = spec
     self.oracle = soda_oracle.Oracle(spec)
 
-  def sweep(self, src, dst, local_dims, iterations, valid_lo, valid_hi):
+  def sweep(self, src, dst, local_dims, iterations, valid_lo, valid_hi, rows=None):
     spec = self.spec
     name_in = spec['inputs'][0]['name']
     name_out = spec['outputs'][0]
+    if rows is not None:    # the sub-array of those rows, as HipEngine does it
+      local_dims = list(local_dims[:-1]) + [rows[1] - rows[0]]
+      src, dst = src[rows[0]:rows[1]], dst[rows[0]:rows[1]]
     cur = src.numpy()
     boxes = soda_oracle.iteration_boxes(spec, iterations)
     locals_ = {s['name']: np.zeros_like(cur, dtype=self.oracle.dtype(s['name']))
@@ -44,26 +47,37 @@ class OracleEngine:
                  for n, (lo, hi) in boxes[k].items()}
       self.oracle._call(arrays, tuple(local_dims), shifted)
       cur = out
-    dst.copy_(torch.from_numpy(cur))
+    # like the kernels: only the valid box is written
+    lo, hi = boxes[iterations - 1][name_out]
+    box = tuple(slice(vl - l, n - vh - h) for l, h, vl, vh, n in reversed(list(zip(
+        lo, hi, valid_lo, valid_hi, local_dims))))
+    dst[box] = torch.from_numpy(cur)[box]
+
+
+class BandsFirst(sdist.SerialSchedule):
+  """The overlapping schedule's ORDER without streams: bands, exchange of the
+  next super-step, interior - what StreamSchedule runs concurrently on a GPU."""
+  overlapped = True
 
 
 def main():
-  app, w, h, iterate, exchange, out_dir = sys.argv[1:7]
-  w, h, iterate, exchange = int(w), int(h), int(iterate), int(exchange)
+  app, size, iterate, exchange, out_dir = sys.argv[1:6]
+  overlapped = len(sys.argv) > 6 and sys.argv[6] == 'overlap'
+  dims = [int(v) for v in size.split('x')]
+  iterate, exchange = int(iterate), int(exchange)
   rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
   dist.init_process_group(backend='gloo')
   st = frontend.load(os.path.join(ROOT, 'tests', 'samples', app + '.soda'),
                      iterate=iterate)
   spec = specmod.spec_from_stencil(st)
-  dims = [w, h]
   r_lo, r_hi = spec['radius']['lo'][-1], spec['radius']['hi'][-1]
   plan = sdist.SlabPlan(dims, rank, world, r_lo, r_hi, exchange)
   dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
   rng = np.random.default_rng(99)
   if dt.kind == 'f':
-    full = rng.random((h, w), dtype=np.float32).astype(dt)
+    full = rng.random(tuple(reversed(dims)), dtype=np.float32).astype(dt)
   else:
-    full = rng.integers(0, 65536, size=(h, w)).astype(dt)
+    full = rng.integers(0, 65536, size=tuple(reversed(dims))).astype(dt)
   shape = tuple(reversed(plan.local_dims))
   a = torch.zeros(shape, dtype=torch.from_numpy(full[:1]).dtype)
   a[plan.ghost_lo:plan.ghost_lo + plan.own] = torch.from_numpy(
@@ -72,15 +86,16 @@ def main():
   table = specmod.iteration_margins(spec, iterate)
 
   def margins_of(k):
-    return ((0, 0), (0, 0)) if k == 0 else table[k - 1]
+    return ((0,) * len(dims), (0,) * len(dims)) if k == 0 else table[k - 1]
 
+  order = BandsFirst() if overlapped else None
   result, exchanges = sdist.run_slab(OracleEngine(spec), plan, [a, b, c], iterate,
-                                     margins_of, dist)
+                                     margins_of, dist, schedule=order)
   own = result[plan.ghost_lo:plan.ghost_lo + plan.own].numpy().copy()
   # A was not written and now carries the neighbours' level-0 rows: a second
   # sweep may skip its first exchange and must give the same rows
   again, fewer = sdist.run_slab(OracleEngine(spec), plan, [a, b, c], iterate,
-                                margins_of, dist, ghosts_ready=True)
+                                margins_of, dist, ghosts_ready=True, schedule=order)
   assert fewer == exchanges - 1, (fewer, exchanges)
   assert np.array_equal(again[plan.ghost_lo:plan.ghost_lo + plan.own].numpy(), own)
   np.save(os.path.join(out_dir, 'rank%d.npy' % rank), own)

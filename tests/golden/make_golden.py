@@ -157,7 +157,25 @@ class Reader:
       self.take(',')
       idx.append(self.sint())
     self.take(')')
-    return ir.Ref(name=name, idx=idx, lat=None)
+    lat = None
+    if self.peek()[1] == '~' and self.peek(1)[0] == 'int':   # `('~' lat=Int)?`
+      self.take('~')
+      lat = self.sint()
+    return ir.Ref(name=name, idx=idx, lat=lat)
+
+  def lets(self):
+    """`(let=Let)*` in front of the stored reference: `[Type] name = Expr`."""
+    out = []
+    while True:
+      (k0, t0), (k1, t1), (k2, t2) = self.peek(), self.peek(1), self.peek(2)
+      if k0 == 'id' and TYPE_RE.match(t0) and k1 == 'id' and t2 == '=':
+        self.take(); name = self.take(); self.take('=')
+        out.append(ir.Let(haoda_type=t0, name=name, expr=self.level()))
+      elif k0 == 'id' and t1 == '=':
+        name = self.take(); self.take('=')
+        out.append(ir.Let(haoda_type=None, name=name, expr=self.level()))
+      else:
+        return out
 
 
 STMT = re.compile(r'^(kernel|burst\s+width|unroll\s+factor|iterate|input|local'
@@ -191,12 +209,13 @@ def read_program(text):
       prog['inputs'].append(stmt)
     else:
       rd = Reader(body)
+      lets = rd.lets()
       ref = rd.ref()
       rd.take('=')
       expr = rd.level()
       assert rd.peek() == (None, None), rd.peek()
       cls = grammar.LocalStmt if head[0] == 'local' else grammar.OutputStmt
-      kw = dict(haoda_type=head[1], let=[], ref=ref, expr=expr)
+      kw = dict(haoda_type=head[1], let=lets, ref=ref, expr=expr)
       if head[0] == 'output':
         kw['dram'] = []
       stmt = cls(**kw)
@@ -215,9 +234,11 @@ def read_program(text):
   return prog
 
 
-def build_stencil(path, iterate=None):
-  with open(path) as f:
-    prog = read_program(f.read())
+def build_stencil(path, iterate=None, text=None):
+  if text is None:
+    with open(path) as f:
+      text = f.read()
+  prog = read_program(text)
   core._overall_stencil_window_cache.clear()
   st = core.Stencil(
       burst_width=prog['burst_width'],
@@ -287,6 +308,7 @@ C_HEADERS = ('assert', 'float', 'math', 'stdbool', 'stddef', 'stdint', 'stdio',
 CXX_HEADERS = ('algorithm', 'array', 'string', 'unordered_map')
 NP_TYPES = {'uint8_t': np.uint8, 'uint16_t': np.uint16, 'uint32_t': np.uint32,
             'int8_t': np.int8, 'int16_t': np.int16, 'int32_t': np.int32,
+            'int64_t': np.int64, 'uint64_t': np.uint64,
             'float': np.float32, 'double': np.float64}
 
 
@@ -396,7 +418,129 @@ CASES_2D = [(37, 29), (64, 48)]
 CASES_3D = [(20, 18, 16), (33, 9, 12)]
 
 
+EXTRA = os.path.join(os.path.dirname(HERE), 'samples', 'extra')
+
+
+def main_extra():
+  """Fixtures for the hand-written programs of tests/samples/extra (features no
+  reference sample uses: let, casts, ~lat, two-argument C calls, one-sided
+  windows), produced by the reference exactly like the sample fixtures.  Writes
+  extra.*.npz, extra_analysis.json and extra_manifest.json; a program whose
+  reference-emitted CPU loops do not compile is recorded as such."""
+  analysis, manifest = {}, {}
+  with tempfile.TemporaryDirectory() as wd:
+    for fname in sorted(os.listdir(EXTRA)):
+      app = fname[:-5]
+      st = build_stencil(os.path.join(EXTRA, fname))
+      ana, text = analysis_of(st)
+      key = '%s.iter%d' % (app, st.iterate)
+      analysis[key] = ana
+      for dims in [(37, 29), (64, 48)]:
+        for kind in ('ramp', 'random'):
+          inputs = make_inputs(st, dims, kind, np.random.default_rng(SEED))
+          try:
+            r0 = run_reference(st, text, dims, inputs, '-O0', wd)
+            r2 = run_reference(st, text, dims, inputs, '-O2 -ffp-contract=off', wd)
+          except subprocess.CalledProcessError:
+            manifest['extra.' + key] = dict(
+                key=key, reference_cpu_path='does not compile')
+            print(key, ': the reference\'s emitted CPU loops do not compile')
+            break
+          for name in r0:
+            if not np.array_equal(r0[name], r2[name], equal_nan=True):
+              raise SystemExit('O0/O2 disagree: %s %s' % (key, name))
+          fx = 'extra.%s.%s.%s.npz' % (key, 'x'.join(map(str, dims)), kind)
+          payload = {'in_' + n: a for n, a in zip(st.input_names, inputs)}
+          payload.update({'out_' + n: a for n, a in r0.items()})
+          np.savez_compressed(os.path.join(HERE, fx), **payload)
+          manifest[fx] = dict(key=key, dims=list(dims), kind=kind,
+                              sha256={n: hashlib.sha256(a.tobytes()).hexdigest()
+                                      for n, a in r0.items()})
+          print('wrote', fx)
+        else:
+          continue
+        break
+  with open(os.path.join(HERE, 'extra_analysis.json'), 'w') as f:
+    json.dump(analysis, f, indent=1, sort_keys=True)
+  with open(os.path.join(HERE, 'extra_manifest.json'), 'w') as f:
+    json.dump(manifest, f, indent=1, sort_keys=True)
+
+
+def main_random():
+  """The random programs of the GPU tests (tests/random_programs.py; texts in
+  random_programs.json) through the reference: its analysis of each program and,
+  where its emitted CPU loops compile, their result on seeded inputs.  Writes
+  random_analysis.json, random_manifest.json and random.<key>.npz."""
+  with open(os.path.join(HERE, 'random_programs.json')) as f:
+    programs = json.load(f)
+  analysis, manifest = {}, {}
+  with tempfile.TemporaryDirectory() as wd:
+    for key in sorted(programs):
+      entry = programs[key]
+      try:
+        st = build_stencil(None, text=entry['text'])
+        ana, text = analysis_of(st)
+      except Exception as e:      # the reference itself rejects the program
+        manifest['random.' + key] = dict(reference='raises %s' % type(e).__name__)
+        print(key, 'reference raises', type(e).__name__, e)
+        continue
+      for stage in ana['stages']:      # (the point sets are large and derivable)
+        stage.pop('window')
+      analysis[key] = ana
+      if any(min(t['loop_lo'] + t['loop_hi_margin']) < 0 for t in ana['stages']):
+        # a window that excludes the store point: the emitted loops start at a
+        # negative index or print `dims[0]--1`; either way no defined answer
+        manifest['random.' + key] = dict(
+            reference_cpu_path='one-sided window: loops leave the arrays')
+        print(key, ': one-sided window, no defined reference answer')
+        continue
+      deep = st.iterate >= 8
+      dims = ((100, 96) if deep else (45, 41)) if st.dim == 2 else (21, 19, 17)
+      rng = np.random.default_rng(SEED)
+      shape = tuple(reversed(dims))
+      inputs = []
+      for htype in st.input_types:
+        dt = NP_TYPES[hutil.get_c_type(htype)]
+        if np.issubdtype(dt, np.floating):
+          inputs.append((rng.random(shape, dtype=np.float32) +
+                         np.float32(0.5)).astype(dt))
+        else:
+          inputs.append(rng.integers(0, 200, size=shape).astype(dt))
+      # every run starts from a fresh harness tag: programs share app names
+      st_tag = st.app_name
+      st.app_name = '%s_%s' % (st_tag, key)
+      try:
+        r0 = run_reference(st, text, dims, inputs, '-O0', wd)
+        r2 = run_reference(st, text, dims, inputs, '-O2 -ffp-contract=off', wd)
+      except subprocess.CalledProcessError:
+        manifest['random.' + key] = dict(reference_cpu_path='does not compile or run')
+        print(key, ': the reference\'s emitted CPU loops do not compile / run')
+        continue
+      finally:
+        st.app_name = st_tag
+      outs = {n: r0[n] for n in st.output_names}
+      for name in outs:
+        if not np.array_equal(r0[name], r2[name], equal_nan=True):
+          raise SystemExit('O0/O2 disagree: %s %s' % (key, name))
+      fx = 'random.%s.npz' % key
+      payload = {'in_' + n: a for n, a in zip(st.input_names, inputs)}
+      payload.update({'out_' + n: a for n, a in outs.items()})
+      np.savez_compressed(os.path.join(HERE, fx), **payload)
+      manifest[fx] = dict(key=key, dims=list(dims), iterate=st.iterate,
+                          sha256={n: hashlib.sha256(a.tobytes()).hexdigest()
+                                  for n, a in outs.items()})
+      print('wrote', fx)
+  with open(os.path.join(HERE, 'random_analysis.json'), 'w') as f:
+    json.dump(analysis, f, sort_keys=True, separators=(',', ':'))
+  with open(os.path.join(HERE, 'random_manifest.json'), 'w') as f:
+    json.dump(manifest, f, indent=1, sort_keys=True)
+
+
 def main():
+  if len(sys.argv) > 1 and sys.argv[1] == '--extra':
+    return main_extra()
+  if len(sys.argv) > 1 and sys.argv[1] == '--random':
+    return main_random()
   samples = sorted(os.listdir(os.path.join(REF, 'tests/src')))
   analysis = {}
   manifest = {}

@@ -16,8 +16,13 @@ SEED = 20240607
 BLOBS = os.path.join(ROOT, 'soda-compiler_amd', 'blobs')
 
 
+def sample_path(app):
+  path = os.path.join(SAMPLES, app + '.soda')
+  return path if os.path.exists(path) else os.path.join(SAMPLES, 'extra', app + '.soda')
+
+
 def load_spec(app, **overrides):
-  st = frontend.load(os.path.join(SAMPLES, app + '.soda'), **overrides)
+  st = frontend.load(sample_path(app), **overrides)
   return specmod.spec_from_stencil(st)
 
 

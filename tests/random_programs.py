@@ -1,0 +1,115 @@
+"""Generator of random SODA programs for the parity tests: asymmetric and
+one-sided windows, negative-only offsets, fan-in and fan-out DAGs, `let`s, casts,
+integer division, several inputs, 2-D and 3-D.  Plain numpy, so that
+tests/golden/make_golden.py (python3.9, next to the reference) and the tests
+share it.  The texts the committed fixtures were made from are stored with them
+(tests/golden/random_programs.json): numpy does not promise the same random
+stream in every version."""
+import numpy as np
+
+
+def random_program(rng, seed):
+  dim = 3 if rng.random() < 0.25 else 2
+  floaty = rng.random() < 0.6
+  dtype = rng.choice(['float', 'float', 'float', 'double']) if floaty else \
+      rng.choice(['uint16', 'int32', 'int32', 'uint8', 'int64', 'int16'])
+  n_inputs = 1 if rng.random() < 0.75 else 2
+  n_locals = int(rng.integers(0, 4))
+  iterate = int(rng.integers(1, 6)) if n_inputs == 1 else 1
+  reach = 2 if dim == 2 else 1
+  names = ['in%d' % i for i in range(n_inputs)]
+  lines = ['kernel: rnd%d' % seed, 'burst width: 512', 'unroll factor: 2',
+           'iterate: %d' % iterate]
+  tile = ', '.join(['32'] * (dim - 1))
+  for i, n in enumerate(names):
+    lines.append('input %s: %s(%s, *)' % (dtype, n, tile) if i == n_inputs - 1
+                 else 'input %s: %s' % (dtype, n))
+  if n_inputs == 2:   # only the LAST input may carry the tile (reference quirk)
+    lines[-2], lines[-1] = 'input %s: %s' % (dtype, names[0]), \
+        'input %s: %s(%s, *)' % (dtype, names[1], tile)
+
+  def offset():
+    # sometimes one-sided windows: only negative or only positive offsets
+    mode = rng.integers(0, 4)
+    lo, hi = (-reach, reach) if mode < 2 else ((-reach, 0) if mode == 2 else (0, reach))
+    return tuple(int(rng.integers(lo, hi + 1)) for _ in range(dim))
+
+  def load(name):
+    return '%s(%s)' % (name, ', '.join(map(str, offset())))
+
+  def literal():
+    if floaty:
+      return rng.choice(['0.25f', '0.5f', '1.5f', '0.125f', '3.0f', '0.2f', '0.3'])
+    return str(int(rng.integers(1, 5)))
+
+  def expression(available, must_use):
+    terms = []
+    pool = list(must_use) + [rng.choice(available)
+                             for _ in range(int(rng.integers(1, 4)))]
+    for name in pool:
+      t = load(name)
+      r = rng.random()
+      if r < 0.3:
+        t = '%s * %s' % (t, literal())
+      elif r < 0.4:
+        t = '(%s - %s)' % (t, load(rng.choice(available)))
+      elif r < 0.5 and not floaty:
+        t = '(%s + %s) / 3' % (t, load(name))
+      elif r < 0.5 and floaty:
+        t = '%s / %s' % (t, literal())
+      terms.append(t)
+    text = terms[0]
+    for t in terms[1:]:
+      text += rng.choice([' + ', ' - ', ' + ']) + t
+    if rng.random() < 0.3:
+      text = '(%s) * %s' % (text, literal())
+    return text
+
+  available = list(names)
+  unused = list(names)
+  for k in range(n_locals):
+    name = 'loc%d' % k
+    use = [unused.pop(0)] if unused and rng.random() < 0.7 else []
+    if rng.random() < 0.25:
+      lines.append('local %s: t = %s %s(%s) = t + %s' % (
+          dtype, expression(available, use), name, ', '.join(['0'] * dim),
+          load(rng.choice(available))))
+    else:
+      lines.append('local %s: %s(%s) = %s' % (
+          dtype, name, ', '.join(map(str, offset())), expression(available, use)))
+    available.append(name)
+    unused.append(name)
+  # the output reads everything still unused, so that no stage is dead
+  lines.append('output %s: out(%s) = %s' % (
+      dtype, ', '.join(['0'] * dim), expression(available, unused)))
+  return '\n'.join(lines) + '\n', dim, dtype, iterate
+
+
+
+
+def program_set(n_plain=40, n_deep=16):
+  """[(key, text, dim, iterate, shape)] - the programs of the GPU random tests."""
+  out = []
+  for seed in range(n_plain):
+    rng = np.random.default_rng(1000 + seed)
+    text, dim, dtype, iterate = random_program(rng, seed)
+    out.append(('plain%d' % seed, text, dim, iterate))
+  for seed in range(n_deep):
+    rng = np.random.default_rng(5000 + seed)
+    while True:
+      text, dim, dtype, iterate = random_program(rng, seed)
+      if dim == 2 and 'input %s: in1' % dtype not in text:
+        break
+    deep = int(rng.integers(8, 21))
+    text = text.replace('iterate: %d\n' % iterate, 'iterate: %d\n' % deep)
+    out.append(('deep%d' % seed, text, dim, deep))
+  return out
+
+
+if __name__ == '__main__':      # writes the program texts the fixtures are made from
+  import json
+  import os
+  here = os.path.dirname(os.path.abspath(__file__))
+  with open(os.path.join(here, 'golden', 'random_programs.json'), 'w') as f:
+    json.dump({k: dict(text=t, dim=d, iterate=i) for k, t, d, i in program_set()},
+              f, indent=1, sort_keys=True)

@@ -144,13 +144,17 @@ def test_wave_pipelined_forms_compile(options, tmp_path):
 
 
 def test_default_depth_sets():
-  """jacobi2d and seidel2d (plain float programs) get a depth-16 kernel in the
-  packed wave-pipelined form, fed through the LDS ring and therefore limited to
-  arrays at least one strip wide; integer programs stop at depth 12 (their
-  wave-pipelined kernels use the ring too)."""
+  """jacobi2d and seidel2d (plain float programs) get depth-16, -20 and -24
+  kernels (as many as fit the registers) in the packed wave-pipelined form, fed
+  through the LDS ring and therefore limited to arrays at least one strip wide;
+  integer programs stop at depth 12 (their wave-pipelined kernels use the ring
+  too).  Every fused kernel carries the cost figures the scheduler prices it by."""
   table = kernel.generate(spec_of('jacobi2d', iterate=1000))[1]
   fused = {k['depth']: k for k in table if k['kind'] == 'fused'}
-  assert sorted(fused) == [1, 2, 4, 8, 12, 16]
+  assert sorted(fused) == [1, 2, 4, 8, 12, 16, 20, 24]
+  assert all(k['step_valu'] > 0 and k['step_bytes'] > 0 for k in fused.values())
+  assert fused[24]['tile'][0] == 464 and fused[20]['tile'][0] == 472
+  assert fused[24]['fill_rows'] == 51
   assert fused[12]['groups'] == 4 and fused[12]['pairs'] and not fused[8].get('groups')
   k16 = fused[16]
   # wide strips (512 columns per wavefront), 12-slot ring, four workgroups per CU

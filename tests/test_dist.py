@@ -25,14 +25,15 @@ def free_port():
   return port
 
 
-def run_world(tmp_path, world, app, w, h, iterate, exchange):
+def run_world(tmp_path, world, app, dims, iterate, exchange, overlap=False):
   env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()),
              WORLD_SIZE=str(world), OMP_NUM_THREADS='2')
   procs = []
   for rank in range(world):
     procs.append(subprocess.Popen(
         [sys.executable, os.path.join(ROOT, 'tests', 'dist_worker.py'), app,
-         str(w), str(h), str(iterate), str(exchange), str(tmp_path)],
+         'x'.join(map(str, dims)), str(iterate), str(exchange), str(tmp_path)] +
+        (['overlap'] if overlap else []),
         env=dict(env, RANK=str(rank), LOCAL_RANK=str(rank))))
   for p in procs:
     assert p.wait(timeout=300) == 0
@@ -40,13 +41,14 @@ def run_world(tmp_path, world, app, w, h, iterate, exchange):
   spec = specmod.spec_from_stencil(st)
   dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
   rng = np.random.default_rng(99)
+  shape = tuple(reversed(dims))
   if dt.kind == 'f':
-    full = rng.random((h, w), dtype=np.float32).astype(dt)
+    full = rng.random(shape, dtype=np.float32).astype(dt)
   else:
-    full = rng.integers(0, 65536, size=(h, w)).astype(dt)
+    full = rng.integers(0, 65536, size=shape).astype(dt)
   orc = soda_oracle.Oracle(spec)
   want = orc.run([full], iterate=iterate)[spec['outputs'][0]]
-  sl = orc.valid_slices((w, h), iterate)
+  sl = orc.valid_slices(tuple(dims), iterate)
   got = np.zeros_like(want)
   meta = []
   for rank in range(world):
@@ -59,16 +61,26 @@ def run_world(tmp_path, world, app, w, h, iterate, exchange):
   return meta
 
 
-@pytest.mark.parametrize('world,app,w,h,iterate,exchange', [
-    (2, 'jacobi2d', 64, 50, 7, 3),
-    (2, 'jacobi2d', 40, 61, 6, 6),
-    (3, 'jacobi2d', 48, 47, 5, 2),
-    (2, 'seidel2d', 56, 40, 4, 2),
-    (2, 'blur', 70, 44, 3, 1),      # window reaches only towards higher indices
-    (3, 'blur', 70, 45, 4, 3),
+@pytest.mark.parametrize('world,app,dims,iterate,exchange,overlap', [
+    (2, 'jacobi2d', (64, 50), 7, 3, False),
+    (2, 'jacobi2d', (40, 61), 6, 6, False),
+    (3, 'jacobi2d', (48, 47), 5, 2, False),
+    (2, 'seidel2d', (56, 40), 4, 2, False),
+    (2, 'blur', (70, 44), 3, 1, False),   # window reaches only towards higher indices
+    (3, 'blur', (70, 45), 4, 3, False),
+    # 3-D: ghost PLANES
+    (2, 'jacobi3d', (20, 18, 30), 5, 2, False),
+    (3, 'heat3d', (16, 14, 40), 4, 3, False),
+    # the overlapping schedule's order: boundary bands, exchange, interior
+    (2, 'jacobi2d', (64, 70), 9, 3, True),
+    (3, 'jacobi2d', (48, 90), 8, 3, True),
+    (3, 'blur', (70, 75), 6, 2, True),
+    (3, 'jacobi3d', (20, 18, 60), 6, 2, True),
 ])
-def test_slabs_match_single_process(tmp_path, world, app, w, h, iterate, exchange):
-  meta = run_world(tmp_path, world, app, w, h, iterate, exchange)
+def test_slabs_match_single_process(tmp_path, world, app, dims, iterate, exchange,
+                                    overlap):
+  meta = run_world(tmp_path, world, app, dims, iterate, exchange, overlap)
+  h = dims[-1]
   assert meta[0][0] == 0 and meta[-1][1] == h
   for (a0, a1, _, _), (b0, b1, _, _) in zip(meta, meta[1:]):
     assert a1 == b0
@@ -87,8 +99,19 @@ def test_slab_bounds_and_plan():
   # margins: neighbour sides are fully valid, global sides carry the margin
   lo, hi = first.valid_margins(10, lambda k: ((k, k), (k, k)))
   assert (lo, hi) == ([10, 10], [10, 0])
-  assert sdist.auto_exchange(2048, 1, 12, 1000) == 144      # 8 ranks of 16384 rows
-  assert sdist.auto_exchange(8192, 1, 12, 1000) == 144
+  assert sdist.auto_exchange(2048, 1, 24, 1000) == 144      # 8 ranks of 16384 rows
+  assert sdist.auto_exchange(8192, 1, 24, 1000) == 192
   assert sdist.auto_exchange(64, 1, 4, 200) == 4            # 8 ranks of 512 planes
   assert sdist.auto_exchange(64, 1, 12, 1000) == 12
   assert sdist.auto_exchange(2048, 1, 12, 30) == 30
+  # a slab thinner than the stencil reach cannot be exchanged correctly
+  with pytest.raises(ValueError):
+    sdist.SlabPlan([64, 3], 1, 4, 1, 1, 4)
+  # the overlapping schedule's pieces tile the own rows
+  mid = sdist.SlabPlan([16384, 16384], 3, 8, 1, 1, 48)
+  bands, interior = sdist.band_plan(mid, 48)
+  assert bands == [(0, 144, True, True), (2000, 2144, True, True)]
+  assert interior == (48, 2096, True, True)
+  bands, interior = sdist.band_plan(first, 20)
+  assert bands == [(2048 - 48 - 20, 2048 + 20, True, True)]
+  assert interior == (0, 2048 - 48 + 20, False, True)

@@ -3,7 +3,9 @@
 windows, negative-only offsets (stages that run AHEAD of their parents in the
 streaming pipeline), fan-in and fan-out DAGs, `let`s, casts, integer division,
 several inputs, 2-D and 3-D, fused and per-stage kernels, every depth split."""
+import json
 import os
+import tempfile
 
 import numpy as np
 import pytest
@@ -14,91 +16,39 @@ from soda_hip.codegen import spec as specmod
 from soda_hip.runtime import host
 from oracle import soda_oracle
 
+
 pytestmark = pytest.mark.gpu
 
 
-def random_program(rng, seed):
-  dim = 3 if rng.random() < 0.25 else 2
-  floaty = rng.random() < 0.6
-  dtype = rng.choice(['float', 'float', 'float', 'double']) if floaty else \
-      rng.choice(['uint16', 'int32', 'int32', 'uint8', 'int64', 'int16'])
-  n_inputs = 1 if rng.random() < 0.75 else 2
-  n_locals = int(rng.integers(0, 4))
-  iterate = int(rng.integers(1, 6)) if n_inputs == 1 else 1
-  reach = 2 if dim == 2 else 1
-  names = ['in%d' % i for i in range(n_inputs)]
-  lines = ['kernel: rnd%d' % seed, 'burst width: 512', 'unroll factor: 2',
-           'iterate: %d' % iterate]
-  tile = ', '.join(['32'] * (dim - 1))
-  for i, n in enumerate(names):
-    lines.append('input %s: %s(%s, *)' % (dtype, n, tile) if i == n_inputs - 1
-                 else 'input %s: %s' % (dtype, n))
-  if n_inputs == 2:   # only the LAST input may carry the tile (reference quirk)
-    lines[-2], lines[-1] = 'input %s: %s' % (dtype, names[0]), \
-        'input %s: %s(%s, *)' % (dtype, names[1], tile)
-
-  def offset():
-    # sometimes one-sided windows: only negative or only positive offsets
-    mode = rng.integers(0, 4)
-    lo, hi = (-reach, reach) if mode < 2 else ((-reach, 0) if mode == 2 else (0, reach))
-    return tuple(int(rng.integers(lo, hi + 1)) for _ in range(dim))
-
-  def load(name):
-    return '%s(%s)' % (name, ', '.join(map(str, offset())))
-
-  def literal():
-    if floaty:
-      return rng.choice(['0.25f', '0.5f', '1.5f', '0.125f', '3.0f', '0.2f', '0.3'])
-    return str(int(rng.integers(1, 5)))
-
-  def expression(available, must_use):
-    terms = []
-    pool = list(must_use) + [rng.choice(available)
-                             for _ in range(int(rng.integers(1, 4)))]
-    for name in pool:
-      t = load(name)
-      r = rng.random()
-      if r < 0.3:
-        t = '%s * %s' % (t, literal())
-      elif r < 0.4:
-        t = '(%s - %s)' % (t, load(rng.choice(available)))
-      elif r < 0.5 and not floaty:
-        t = '(%s + %s) / 3' % (t, load(name))
-      elif r < 0.5 and floaty:
-        t = '%s / %s' % (t, literal())
-      terms.append(t)
-    text = terms[0]
-    for t in terms[1:]:
-      text += rng.choice([' + ', ' - ', ' + ']) + t
-    if rng.random() < 0.3:
-      text = '(%s) * %s' % (text, literal())
-    return text
-
-  available = list(names)
-  unused = list(names)
-  for k in range(n_locals):
-    name = 'loc%d' % k
-    use = [unused.pop(0)] if unused and rng.random() < 0.7 else []
-    if rng.random() < 0.25:
-      lines.append('local %s: t = %s %s(%s) = t + %s' % (
-          dtype, expression(available, use), name, ', '.join(['0'] * dim),
-          load(rng.choice(available))))
-    else:
-      lines.append('local %s: %s(%s) = %s' % (
-          dtype, name, ', '.join(map(str, offset())), expression(available, use)))
-    available.append(name)
-    unused.append(name)
-  # the output reads everything still unused, so that no stage is dead
-  lines.append('output %s: out(%s) = %s' % (
-      dtype, ', '.join(['0'] * dim), expression(available, unused)))
-  return '\n'.join(lines) + '\n', dim, dtype, iterate
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+with open(os.path.join(GOLDEN, 'random_programs.json')) as f:
+  PROGRAMS = json.load(f)          # the texts the reference fixtures were made from
+with open(os.path.join(GOLDEN, 'random_manifest.json')) as f:
+  REFERENCE = {v['key']: (k, v) for k, v in json.load(f).items() if k.endswith('.npz')}
+SCRATCH = tempfile.mkdtemp(prefix='soda_oracle_')      # not oracle/_build
 
 
-def run_case(text, dim, iterate, seed, shape, rng):
+def run_case(key, shape, rng):
+  """One random program through the HIP back end (hiprtc), every depth split:
+  (a) on the inputs of the REFERENCE's own run of this program, against the
+  reference's result (tests/golden/random.<key>.npz, made by `make_golden.py
+  --random`; 28 of the 56 programs - the others have a window that excludes the
+  store point, for which the reference's loops leave the arrays or do not compile);
+  (b) on a larger grid against the CPU oracle."""
+  entry = PROGRAMS[key]
+  text, iterate = entry['text'], entry['iterate']
   stencil = frontend.loads(text)
   spec = specmod.spec_from_stencil(stencil)
   src, table = kernel.generate(spec)
   prog = host.open_program(source=src, spec=spec)
+  fused = [k['depth'] for k in table if k['kind'] == 'fused']
+  cases = []
+  if key in REFERENCE:
+    fixture, meta = REFERENCE[key]
+    data = np.load(os.path.join(GOLDEN, fixture))
+    ins = [np.ascontiguousarray(data['in_' + t['name']]) for t in spec['inputs']]
+    cases.append((ins, data['out_out'], 'reference fixture'))
+  orc = soda_oracle.Oracle(spec, build_dir=SCRATCH)
   inputs = []
   for t in spec['inputs']:
     dt = np.dtype(specmod.NUMPY_NAME[t['c_type']])
@@ -106,18 +56,17 @@ def run_case(text, dim, iterate, seed, shape, rng):
       inputs.append((rng.random(shape, dtype=np.float32) + np.float32(0.5)).astype(dt))
     else:
       inputs.append(rng.integers(0, 200, size=shape).astype(dt))
-  orc = soda_oracle.Oracle(spec)
-  want = orc.run(inputs, iterate=iterate)['out']
-  sl = orc.valid_slices(tuple(reversed(shape)), iterate)
-  fused = [k['depth'] for k in table if k['kind'] == 'fused']
-  for max_depth in sorted({0, 1, -1} if fused else {-1}):
-    prog.set_max_depth(max_depth)
-    got = prog.run_numpy(inputs, iterate=iterate)[0]
-    if want[sl].size == 0:
-      continue
-    same = np.array_equal(got[sl], want[sl], equal_nan=True)
-    assert same, 'seed %d max_depth %d (fused depths %s)\n%s' % (
-        seed, max_depth, fused, text)
+  cases.append((inputs, orc.run(inputs, iterate=iterate)['out'], 'oracle'))
+  for ins, want, what in cases:
+    sl = orc.valid_slices(tuple(reversed(ins[0].shape)), iterate)
+    for max_depth in sorted({0, 1, -1} if fused else {-1}):
+      prog.set_max_depth(max_depth)
+      got = prog.run_numpy(ins, iterate=iterate)[0]
+      if want[sl].size == 0:
+        continue
+      same = np.array_equal(got[sl], want[sl], equal_nan=True)
+      assert same, '%s vs %s, max_depth %d (fused depths %s)\n%s' % (
+          key, what, max_depth, fused, text)
   prog.close()
   prog.blob.unload()
   return table
@@ -126,8 +75,8 @@ def run_case(text, dim, iterate, seed, shape, rng):
 @pytest.mark.parametrize('seed', range(int(os.environ.get('SODA_RANDOM_SEEDS', '40'))))
 def test_random_program(seed):
   rng = np.random.default_rng(1000 + seed)
-  text, dim, dtype, iterate = random_program(rng, seed)
-  run_case(text, dim, iterate, seed, (41, 333) if dim == 2 else (19, 23, 150), rng)
+  key = 'plain%d' % seed
+  run_case(key, (41, 333) if PROGRAMS[key]['dim'] == 2 else (19, 23, 150), rng)
 
 
 @pytest.mark.parametrize('seed', range(int(os.environ.get('SODA_RANDOM_DEEP_SEEDS', '16'))))
@@ -135,11 +84,4 @@ def test_random_program_many_iterations(seed):
   """The same generator with `iterate` 8..20: deep fused kernels, among them
   the wave-pipelined and packed forms the generator picks for chains that do not
   fit one wavefront's registers."""
-  rng = np.random.default_rng(5000 + seed)
-  while True:
-    text, dim, dtype, iterate = random_program(rng, seed)
-    if dim == 2 and 'input %s: in1' % dtype not in text:
-      break
-  deep = int(rng.integers(8, 21))
-  text = text.replace('iterate: %d\n' % iterate, 'iterate: %d\n' % deep)
-  run_case(text, dim, deep, seed, (400, 700), rng)
+  run_case('deep%d' % seed, (400, 700), np.random.default_rng(5000 + seed))

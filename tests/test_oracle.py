@@ -16,18 +16,33 @@ from conftest import GOLDEN, SAMPLES
 
 with open(os.path.join(GOLDEN, 'manifest.json')) as f:
   MANIFEST = json.load(f)
+# hand-written programs (let, casts, ~lat, C calls) run by the reference:
+# `make_golden.py --extra`
+with open(os.path.join(GOLDEN, 'extra_manifest.json')) as f:
+  EXTRA = json.load(f)
+MANIFEST.update({k: v for k, v in EXTRA.items() if k.endswith('.npz')})
+
+# the random programs of the GPU tests, run by the reference where its emitted
+# loops compile: `make_golden.py --random`
+with open(os.path.join(GOLDEN, 'random_manifest.json')) as f:
+  RANDOM = {k: v for k, v in json.load(f).items() if k.endswith('.npz')}
+with open(os.path.join(GOLDEN, 'random_programs.json')) as f:
+  RANDOM_PROGRAMS = json.load(f)
 
 _ORACLES = {}
 
 
 def oracle_for(app):
   if app not in _ORACLES:
-    st = frontend.load(os.path.join(SAMPLES, app + '.soda'))
+    path = os.path.join(SAMPLES, app + '.soda')
+    if not os.path.exists(path):
+      path = os.path.join(SAMPLES, 'extra', app + '.soda')
+    st = frontend.load(path)
     _ORACLES[app] = soda_oracle.Oracle(specmod.spec_from_stencil(st))
   return _ORACLES[app]
 
 
-@pytest.mark.parametrize('fixture', sorted(k for k in MANIFEST if 'in_' or True))
+@pytest.mark.parametrize('fixture', sorted(MANIFEST))
 def test_oracle_matches_reference_fixture(fixture):
   meta = MANIFEST[fixture]
   app, it = meta['key'].split('.iter')
@@ -54,6 +69,22 @@ def test_oracle_matches_reference_fixture(fixture):
   sl = orc.valid_slices(dims, it)
   for name in spec['outputs']:
     assert np.array_equal(pp[name][sl], expected[name][sl], equal_nan=True)
+
+
+@pytest.mark.parametrize('fixture', sorted(RANDOM))
+def test_oracle_matches_reference_on_random_programs(fixture):
+  meta = RANDOM[fixture]
+  st = frontend.loads(RANDOM_PROGRAMS[meta['key']]['text'])
+  spec = specmod.spec_from_stencil(st)
+  orc = soda_oracle.Oracle(spec, build_dir=os.environ.get('TMPDIR', '/tmp'))
+  data = np.load(os.path.join(GOLDEN, fixture))
+  inputs = [np.ascontiguousarray(data['in_' + t['name']]) for t in spec['inputs']]
+  got = orc.run(inputs, iterate=meta['iterate'], keep_all=True)
+  for name in spec['outputs']:
+    want = data['out_' + name]
+    assert got[name].dtype == want.dtype
+    assert np.array_equal(got[name], want, equal_nan=True), (fixture, name)
+    assert hashlib.sha256(got[name].tobytes()).hexdigest() == meta['sha256'][name]
 
 
 def test_reference_ramp_is_what_fixtures_used():
