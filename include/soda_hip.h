@@ -163,6 +163,12 @@ typedef struct soda_hip_kernel {
   int32_t step_valu;  /* VALU issue cycles ONE workgroup (all its wavefronts
                          together) spends per streamed row / plane */
   int32_t step_bytes; /* HBM bytes one workgroup loads + stores per step */
+  int32_t xcd_tiles;  /* 1: the kernel takes a 1-D grid and places its tiles
+                         itself, XCD by XCD: the launcher cuts the plane of tiles
+                         (dimensions 0 and 1) into super-tiles of SX x SY tiles,
+                         passes param[1] = SX | SY << 16 and param[2] = (super-
+                         tiles along x) | (along y) << 16, and launches
+                         ceil(super-tiles x chunks / 8) x 8 x SX x SY workgroups */
 } soda_hip_kernel;
 
 /* By-value argument of every generated kernel. */
@@ -172,7 +178,8 @@ typedef struct soda_hip_args {
   int64_t box_lo[SODA_HIP_MAX_DIMS];  /* cells to produce: [box_lo, box_hi) */
   int64_t box_hi[SODA_HIP_MAX_DIMS];
   int64_t param[4]; /* param[0]: outer-dimension rows per workgroup, chosen per
-                       launch so that the grid fills the chip in whole rounds */
+                       launch so that the grid fills the chip in whole rounds;
+                       param[1], param[2]: see soda_hip_kernel.xcd_tiles */
 } soda_hip_args;
 
 /* ---- plan -------------------------------------------------------------------
@@ -242,6 +249,45 @@ int soda_hip_plan_schedule(soda_hip_plan* plan,
 /* Restricts fused kernels to depth <= max_depth (0 = no limit); for tests and
  * tuning. */
 int soda_hip_plan_set_max_depth(soda_hip_plan* plan, int max_depth);
+
+/* ---- multi-GPU: one slab of a larger grid ------------------------------------
+ * The reference has nothing distributed (one FPGA); what must be preserved is its
+ * semantics: no boundary condition, the valid box shrinks every iteration
+ * (core.py:794-835, host.py:1082-1091), hence an OPEN chain of slabs along the
+ * outermost dimension.  One process (or thread) per GPU owns rows
+ * [own_first, own_last) of that dimension and keeps `exchange * reach` ghost rows
+ * on each side that has a neighbour.  Per super-step of `exchange` iterations:
+ * neighbours swap ghost rows (ncclSend / ncclRecv inside one group, on `stream`),
+ * then the slab advances `exchange` iterations with soda_hip_sweep, the ghost
+ * sides declared valid and the global sides carrying the margin of the iterations
+ * done so far.  Same logic as soda_hip/runtime/dist.py (the torch.distributed
+ * driver, covered by world-size 2 and 3 tests); this entry exists so that a C or
+ * C++ caller - the generated `<app>()` - can shard without Python.  librccl.so is
+ * loaded on first use.  NOTE: with world > 1 this path has not run on hardware
+ * yet (no multi-GPU box was available); world == 1 is tested. */
+typedef struct soda_hip_slab {
+  int32_t rank, world;
+  int32_t reach_lo, reach_hi; /* per-iteration stencil reach along the outermost
+                                 dimension towards lower / higher indices
+                                 (soda_hip_plan_margins(plan, 1)) */
+  int32_t exchange;           /* iterations between ghost exchanges (>= 1) */
+  int64_t dims[SODA_HIP_MAX_DIMS]; /* the GLOBAL grid */
+  int64_t own_first, own_last;     /* this rank's rows of the outermost dimension */
+} soda_hip_slab;
+
+/* extents of the rank's local arrays (own rows + ghost rows) and the ghost depths */
+int soda_hip_slab_extent(const soda_hip_plan* plan, const soda_hip_slab* slab,
+                         int64_t local_dims[SODA_HIP_MAX_DIMS], int64_t* ghost_lo,
+                         int64_t* ghost_hi);
+
+/* a: level-0 slab (own rows at [ghost_lo, ghost_lo + own), ghost rows anything),
+ * never written except for its ghost rows; b, c: two more arrays of the same
+ * size.  comm: an ncclComm_t of `world` ranks (NULL when world == 1).  *result
+ * receives b or c, whichever holds the rank's own rows after `iterate`
+ * iterations.  Asynchronous on `stream`. */
+int soda_hip_run_slab(soda_hip_plan* plan, const soda_hip_slab* slab, void* comm,
+                      void* a, void* b, void* c, int iterate, void* stream,
+                      void** result, int* exchanges);
 
 /* ---- host-buffer entry (the generated `<app>`) ------------------------------
  * Legacy Halide buffer_t, bit-compatible with the struct the reference's

@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -45,6 +47,15 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Experiment knobs (chunk length, XCD super-tile shape, schedule trace) are read
+// from the environment ONLY when SODA_HIP_TUNING=1 is set as well: tools/ set it,
+// nothing else does, so a stray variable cannot change how a production run is
+// scheduled.  None of them can change results, only placement and chunking.
+const char* tuning_env(const char* name) {
+  const char* on = getenv("SODA_HIP_TUNING");
+  return (on && on[0] == '1') ? getenv(name) : nullptr;
+}
 
 struct Box {
   int32_t lo[SODA_HIP_MAX_DIMS];  // <= 0
@@ -287,6 +298,68 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
                   (long long)g);
     out->grid[d] = (unsigned)g;
   }
+  if (desc.xcd_tiles && dim == 3) {
+    // XCD-aware placement (kernel_stream3d_wp.py, xcd_tiles): the plane of
+    // gx x gy tiles is cut into super-tiles of SX x SY tiles whose workgroups run
+    // together on one XCD and share its L2.  Pick the shape that fetches least:
+    // padding (tiles beyond the edge) x halo and cache-line slack amortised over
+    // the super-tile.
+    const int64_t gx = out->grid[0], gy = out->grid[1], gz = out->grid[2];
+    const double w = desc.tile[0], r = desc.tile[1];
+    const double line = 128.0 / std::max(1, plan->prog.elem_size[0]);
+    const double hx = std::max(0, desc.min_extent[0] - desc.tile[0]) + 0.75 * line;
+    const double hy = std::max(0, desc.min_extent[1] - desc.tile[1]);
+    // Super-tiles are dealt whole, so a shape is only eligible if the busiest XCD
+    // gets no more workgroups than it holds at once where the plain deal fits the
+    // chip (jacobi3d 512^3, 9 x 21 x 4 tiles on 768 slots: 3 x 7 puts 105 tiles
+    // on four of the XCDs and 84 on the others - 500 us per launch against 379;
+    // 1 x 3 puts 96 on each - 351 us), or 3 % more than its even share otherwise.
+    const int64_t real = gx * gy * gz;
+    const int64_t slots = std::max<int64_t>(1, plan->resident_blocks[k] / 8);
+    const int64_t even = (real + 7) / 8;
+    const int64_t limit = even <= slots ? slots : even + even * 3 / 100;
+    int best_sx = 1, best_sy = 1;
+    double best = -1;
+    // at most 3 tiles per super-tile: larger groups cut the PMC read bytes further
+    // (jacobi3d x200: reads 2.5x -> 1.7x the written bytes with groups up to 24)
+    // but every one measured ran SLOWER (cfg5 6.2 -> 7.0-7.4 ms), also with the
+    // XCDs evenly loaded; 1 x 3 / 3 x 1 are neutral to 7 % faster per launch
+    int max_group = 3;
+    if (const char* env = tuning_env("SODA_HIP_XCD_GROUP")) max_group = std::max(1, atoi(env));
+    for (int sx = 1; sx <= 8; ++sx)
+      for (int sy = 1; sy <= 8; ++sy) {
+        if (sx * sy > max_group) continue;
+        const int64_t nsx = (gx + sx - 1) / sx, nsy = (gy + sy - 1) / sy;
+        // real tiles per XCD: super-tile g -> XCD g % 8; edge super-tiles are partial
+        int64_t per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int64_t g = 0; g < nsx * nsy * gz; ++g) {
+          const int64_t tx = std::min<int64_t>(sx, gx - (g % nsx) * sx);
+          const int64_t ty = std::min<int64_t>(sy, gy - ((g / nsx) % nsy) * sy);
+          per_xcd[g % 8] += tx * ty;
+        }
+        if (*std::max_element(per_xcd, per_xcd + 8) > limit) continue;
+        const double cost = (1 + hx / (std::min<int64_t>(sx, gx) * w)) *
+                            (1 + hy / (std::min<int64_t>(sy, gy) * r));
+        if (best < 0 || cost < best) { best = cost; best_sx = sx; best_sy = sy; }
+      }
+    if (const char* env = tuning_env("SODA_HIP_XCD_TILES")) {   // tuning: "SX,SY"
+      int sx = 0, sy = 0;
+      if (sscanf(env, "%d,%d", &sx, &sy) == 2 && sx > 0 && sy > 0) { best_sx = sx; best_sy = sy; }
+    }
+    if (tuning_env("SODA_HIP_DEBUG"))
+      fprintf(stderr, "soda_hip: %s: %lld x %lld x %lld tiles, super-tiles of %d x %d\n",
+              desc.name, (long long)gx, (long long)gy, (long long)gz, best_sx, best_sy);
+    const int64_t nsx = (gx + best_sx - 1) / best_sx, nsy = (gy + best_sy - 1) / best_sy;
+    const int64_t supers = nsx * nsy * gz;
+    const int64_t total = (supers + 7) / 8 * 8 * best_sx * best_sy;
+    if (total > 2147483647LL || nsx > 65535 || nsy > 65535)
+      return fail(SODA_HIP_ERR_EXTENTS_TOO_LARGE, "grid of kernel %s would be %lld",
+                  desc.name, (long long)total);
+    out->args.param[1] = best_sx | (best_sy << 16);
+    out->args.param[2] = nsx | (nsy << 16);
+    out->grid[0] = (unsigned)total;
+    out->grid[1] = out->grid[2] = 1;
+  }
   return 0;
 }
 
@@ -430,7 +503,7 @@ int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
       }
     }
     const int m = (int)seq.size();
-    if (getenv("SODA_HIP_DEBUG")) {
+    if (tuning_env("SODA_HIP_DEBUG")) {
       fprintf(stderr, "soda_hip: %d iteration(s) =", iterate);
       for (int k : seq) fprintf(stderr, " %d", plan->kernels[k].depth);
       fprintf(stderr, "  (%s;", priced ? "cost model" : "greedy");
@@ -809,7 +882,7 @@ int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* progra
       if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(
               &api, pl->funcs[k], threads, 0) == hipSuccess && api > 0)
         per_cu = api;
-      if (getenv("SODA_HIP_DEBUG"))
+      if (tuning_env("SODA_HIP_DEBUG"))
         fprintf(stderr, "soda_hip: kernel %s: %d VGPRs, %d workgroup(s) of %d "
                 "wavefronts per CU\n", pl->kernels[k].name, regs, per_cu,
                 waves_per_block);
@@ -823,8 +896,8 @@ int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* progra
       return fail(SODA_HIP_ERR_CONSTRAINT, "kernel %d has a bad block shape", k);
     }
   }
-  if (const char* env = getenv("SODA_HIP_CHUNK_ROWS")) pl->chunk_rows_override = atoi(env);
-  if (const char* env = getenv("SODA_HIP_CHUNK_MIN"))
+  if (const char* env = tuning_env("SODA_HIP_CHUNK_ROWS")) pl->chunk_rows_override = atoi(env);
+  if (const char* env = tuning_env("SODA_HIP_CHUNK_MIN"))
     pl->chunk_rows_min = std::max(4, atoi(env));
   *plan = pl;
   return 0;
@@ -955,6 +1028,150 @@ int soda_hip_sweep_timed(soda_hip_plan* plan, void* const* in, void* const* out,
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);
   return rc;
+}
+
+// ------------------------------------------------------- multi-GPU slab driver
+namespace {
+
+// RCCL is resolved at first use: a single-GPU caller never loads it.
+struct Rccl {
+  int (*group_start)() = nullptr;
+  int (*group_end)() = nullptr;
+  int (*send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*error_string)(int) = nullptr;
+  bool ok = false;
+};
+
+const Rccl& rccl() {
+  static Rccl r = [] {
+    Rccl x;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return x;
+    x.group_start = (int (*)())dlsym(h, "ncclGroupStart");
+    x.group_end = (int (*)())dlsym(h, "ncclGroupEnd");
+    x.send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
+    x.recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
+    x.error_string = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    x.ok = x.group_start && x.group_end && x.send && x.recv;
+    return x;
+  }();
+  return r;
+}
+
+struct SlabGeometry {
+  int64_t own, ghost_lo, ghost_hi, extent, row_bytes;
+  bool has_lo, has_hi;
+};
+
+int slab_geometry(const soda_hip_plan* plan, const soda_hip_slab* s, SlabGeometry* g) {
+  const soda_hip_program& p = plan->prog;
+  if (p.n_inputs != 1 || p.n_outputs != 1)
+    return fail(SODA_HIP_ERR_CONSTRAINT, "slabs: one-input one-output programs");
+  if (s->world < 1 || s->rank < 0 || s->rank >= s->world || s->exchange < 1 ||
+      s->reach_lo < 0 || s->reach_hi < 0)
+    return fail(SODA_HIP_ERR_CONSTRAINT, "slab descriptor out of range");
+  g->own = s->own_last - s->own_first;
+  g->has_lo = s->rank > 0;
+  g->has_hi = s->rank < s->world - 1;
+  g->ghost_lo = g->has_lo ? (int64_t)s->exchange * s->reach_lo : 0;
+  g->ghost_hi = g->has_hi ? (int64_t)s->exchange * s->reach_hi : 0;
+  // a ghost region deeper than a neighbour's own rows would ship rows it does
+  // not own (runtime/dist.py: SlabPlan raises for the same reason)
+  if (g->own < 1 || (s->world > 1 && g->own < (int64_t)s->exchange *
+                                                 std::max(s->reach_lo, s->reach_hi)))
+    return fail(SODA_HIP_ERR_CONSTRAINT,
+                "slab of %lld own rows is thinner than its ghost regions (%d x %d)",
+                (long long)g->own, s->exchange, std::max(s->reach_lo, s->reach_hi));
+  g->extent = g->ghost_lo + g->own + g->ghost_hi;
+  g->row_bytes = p.elem_size[0];
+  for (int d = 0; d < p.dim - 1; ++d) g->row_bytes *= s->dims[d];
+  return 0;
+}
+
+}  // namespace
+
+int soda_hip_slab_extent(const soda_hip_plan* plan, const soda_hip_slab* slab,
+                         int64_t local_dims[SODA_HIP_MAX_DIMS], int64_t* ghost_lo,
+                         int64_t* ghost_hi) {
+  if (!plan || !slab || !local_dims) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  SlabGeometry g;
+  int rc = slab_geometry(plan, slab, &g);
+  if (rc) return rc;
+  for (int d = 0; d < SODA_HIP_MAX_DIMS; ++d)
+    local_dims[d] = d < plan->prog.dim ? slab->dims[d] : 1;
+  local_dims[plan->prog.dim - 1] = g.extent;
+  if (ghost_lo) *ghost_lo = g.ghost_lo;
+  if (ghost_hi) *ghost_hi = g.ghost_hi;
+  return 0;
+}
+
+int soda_hip_run_slab(soda_hip_plan* plan, const soda_hip_slab* slab, void* comm,
+                      void* a, void* b, void* c, int iterate, void* stream,
+                      void** result, int* exchanges) {
+  if (!plan || !slab || !a || !b || !c || !result)
+    return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  if (iterate < 1) return fail(SODA_HIP_ERR_CONSTRAINT, "iterate must be >= 1");
+  SlabGeometry g;
+  int rc = slab_geometry(plan, slab, &g);
+  if (rc) return rc;
+  const soda_hip_program& p = plan->prog;
+  const int last = p.dim - 1;
+  if (slab->world > 1 && !comm)
+    return fail(SODA_HIP_ERR_NULL_ARGUMENT, "world %d needs an RCCL communicator", slab->world);
+  if (slab->world > 1 && !rccl().ok)
+    return fail(SODA_HIP_ERR_NO_DEVICE, "librccl.so could not be loaded: %s", dlerror());
+  hipStream_t s = as_stream(stream);
+  int64_t local_dims[SODA_HIP_MAX_DIMS] = {1, 1, 1, 1};
+  for (int d = 0; d < p.dim; ++d) local_dims[d] = slab->dims[d];
+  local_dims[last] = g.extent;
+  auto exchange_ghosts = [&](char* array) -> int {
+    if (slab->world == 1) return 0;
+    const Rccl& r = rccl();
+    const int64_t send_down = g.has_lo ? (int64_t)slab->exchange * slab->reach_hi : 0;
+    const int64_t send_up = g.has_hi ? (int64_t)slab->exchange * slab->reach_lo : 0;
+    char* first_own = array + g.ghost_lo * g.row_bytes;
+    char* last_own = first_own + g.own * g.row_bytes;
+    int e = r.group_start();
+    // lower neighbour: it needs our first rows, we need its last ones
+    if (!e && g.has_lo && send_down)
+      e = r.send(first_own, (size_t)(send_down * g.row_bytes), 0, slab->rank - 1, comm, s);
+    if (!e && g.has_lo && g.ghost_lo)
+      e = r.recv(array, (size_t)(g.ghost_lo * g.row_bytes), 0, slab->rank - 1, comm, s);
+    if (!e && g.has_hi && send_up)
+      e = r.send(last_own - send_up * g.row_bytes, (size_t)(send_up * g.row_bytes), 0,
+                 slab->rank + 1, comm, s);
+    if (!e && g.has_hi && g.ghost_hi)
+      e = r.recv(last_own, (size_t)(g.ghost_hi * g.row_bytes), 0, slab->rank + 1, comm, s);
+    const int e2 = r.group_end();
+    if (e || e2)
+      return fail(SODA_HIP_ERR_DEVICE_RUN, "RCCL ghost exchange failed: %s",
+                  r.error_string ? r.error_string(e ? e : e2) : "?");
+    return 0;
+  };
+  void* src = a;
+  void* cycle[2] = {b, c};
+  int done = 0, k = 0, count = 0;
+  while (done < iterate) {
+    if ((rc = exchange_ghosts((char*)src))) return rc;
+    count += slab->world > 1;
+    const int step = std::min(slab->exchange, iterate - done);
+    // valid region of the slab's input: ghost sides are fully valid, the global
+    // sides carry the margin of the iterations done so far
+    int32_t lo[SODA_HIP_MAX_DIMS], hi[SODA_HIP_MAX_DIMS];
+    output_margins(plan, done, lo, hi);
+    if (g.has_lo) lo[last] = 0;
+    if (g.has_hi) hi[last] = 0;
+    void* dst = cycle[k % 2];
+    if ((rc = soda_hip_sweep(plan, &src, &dst, local_dims, step, lo, hi, stream))) return rc;
+    src = dst;
+    done += step;
+    ++k;
+  }
+  *result = src;
+  if (exchanges) *exchanges = count;
+  return 0;
 }
 
 // ------------------------------------------------- host-buffer entry point

@@ -163,6 +163,109 @@ def print_selfcheck(spec, out):
   w('  return error_count;\n}\n\n')
 
 
+def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
+  """`<app>_multi_gpu`: the grid cut into slabs along the outermost dimension,
+  all GPUs of the node driven from ONE process, one thread per GPU
+  (ncclCommInitAll + soda_hip_run_slab).  Compiled in with -DSODA_HIP_MULTI_GPU
+  (needs -lrccl -lpthread).  Same protocol as `<app>`: caller owns the host
+  arrays, only the valid interior of the output is written."""
+  w('#ifdef SODA_HIP_MULTI_GPU\n#include <rccl/rccl.h>\n#include <thread>\n'
+    '#include <vector>\n')
+  w('extern "C" int %s_multi_gpu(buffer_t* var_%s_buffer, buffer_t* var_%s_buffer, '
+    'const char* blob, int iterate, int ngpu) {\n' % (app, name_in, name_out))
+  w('  const int dim = %d, last = dim - 1;\n' % dim)
+  w('  int count = 0;\n  soda_hip_device_count(&count);\n')
+  w('  if (ngpu > count) ngpu = count;\n')
+  w('  if (ngpu < 1) return SODA_HIP_ERR_NO_DEVICE;\n')
+  w('  buffer_t* in = var_%s_buffer; buffer_t* out = var_%s_buffer;\n'
+    % (name_in, name_out))
+  w('  const int64_t rows = in->extent[last];\n')
+  w('  if (rows < ngpu) ngpu = (int)rows;\n')
+  w('  std::vector<ncclComm_t> comms(ngpu, nullptr);\n')
+  w('  if (ngpu > 1) {\n    std::vector<int> devs(ngpu);\n'
+    '    for (int i = 0; i < ngpu; ++i) devs[i] = i;\n'
+    '    if (ncclCommInitAll(comms.data(), ngpu, devs.data()) != ncclSuccess) {\n'
+    '      fprintf(*error_report, "ERROR: ncclCommInitAll failed\\n");\n'
+    '      return SODA_HIP_ERR_NO_DEVICE;\n    }\n  }\n')
+  w('  std::vector<int> status(ngpu, 0);\n')
+  w('  auto worker = [&](int rank) {\n')
+  w('    int& rc = status[rank];\n')
+  w('    soda_hip_module* module = nullptr;\n    soda_hip_plan* plan = nullptr;\n')
+  w('    void *a = nullptr, *b = nullptr, *c = nullptr, *result = nullptr;\n')
+  w('    if ((rc = soda_hip_set_device(rank))) return;\n')
+  w('    if ((rc = soda_hip_module_load_file(blob, &module))) return;\n')
+  w('    soda_hip_program program;\n    fill_program(&program);\n')
+  w('    soda_hip_kernel kernels[32];\n    const int n_kernels = fill_kernels(kernels);\n')
+  w('    rc = soda_hip_plan_create(module, &program, kernels, n_kernels, &plan);\n')
+  w('    if (rc == 0) {\n')
+  w('      int32_t lo[4], hi[4];\n      soda_hip_plan_margins(plan, 1, lo, hi);\n')
+  w('      soda_hip_slab slab;\n      memset(&slab, 0, sizeof slab);\n')
+  w('      slab.rank = rank; slab.world = ngpu;\n')
+  w('      slab.reach_lo = lo[last]; slab.reach_hi = hi[last];\n')
+  w('      for (int d = 0; d < dim; ++d) slab.dims[d] = in->extent[d];\n')
+  w('      const int64_t base = rows / ngpu, extra = rows % ngpu;\n')
+  w('      slab.own_first = rank * base + (rank < extra ? rank : extra);\n')
+  w('      slab.own_last = slab.own_first + base + (rank < extra ? 1 : 0);\n')
+  # exchange period: the rule of runtime/dist.py: auto_exchange
+  w('      const int reach = lo[last] > hi[last] ? lo[last] : hi[last];\n')
+  w('      int exchange = %d * 8;   // eight launches of the deepest fused kernel\n'
+    % deepest)
+  w('      while (exchange > %d && (int64_t)exchange * (reach > 0 ? reach : 1) * 2 * 100 > '
+    'base * 15) exchange -= %d;\n' % (deepest, deepest))
+  w('      if (exchange > iterate) exchange = iterate;\n')
+  w('      if (exchange < 1) exchange = 1;\n')
+  w('      slab.exchange = ngpu > 1 ? exchange : iterate;\n')
+  w('      int64_t local[4], ghost_lo = 0, ghost_hi = 0;\n')
+  w('      rc = soda_hip_slab_extent(plan, &slab, local, &ghost_lo, &ghost_hi);\n')
+  w('      size_t row_bytes = (size_t)in->elem_size;\n')
+  w('      for (int d = 0; d < last; ++d) row_bytes *= (size_t)in->extent[d];\n')
+  w('      const size_t bytes = row_bytes * (size_t)local[last];\n')
+  w('      const int64_t own = slab.own_last - slab.own_first;\n')
+  w('      if (!rc) rc = soda_hip_malloc(&a, bytes);\n')
+  w('      if (!rc) rc = soda_hip_malloc(&b, bytes);\n')
+  w('      if (!rc) rc = soda_hip_malloc(&c, bytes);\n')
+  w('      if (!rc) rc = soda_hip_memset(a, 0, bytes, nullptr);\n')
+  w('      if (!rc) rc = soda_hip_memset(b, 0, bytes, nullptr);\n')
+  w('      if (!rc) rc = soda_hip_memset(c, 0, bytes, nullptr);\n')
+  w('      if (!rc) rc = soda_hip_memcpy_h2d((char*)a + ghost_lo * row_bytes, '
+    'in->host + slab.own_first * row_bytes, own * row_bytes, nullptr);\n')
+  w('      if (!rc) rc = soda_hip_stream_synchronize(nullptr);\n')
+  w('      if (!rc) rc = soda_hip_run_slab(plan, &slab, comms[rank], a, b, c, iterate, '
+    'nullptr, &result, nullptr);\n')
+  w('      if (!rc) rc = soda_hip_stream_synchronize(nullptr);\n')
+  w('      if (!rc) {\n')
+  w('        // only the valid interior goes back to the caller (host.py:838-899)\n')
+  w('        std::vector<uint8_t> stage(own * row_bytes);\n')
+  w('        rc = soda_hip_memcpy_d2h(stage.data(), (char*)result + ghost_lo * row_bytes, '
+    'own * row_bytes, nullptr);\n')
+  w('        if (!rc) rc = soda_hip_stream_synchronize(nullptr);\n')
+  w('        int32_t mlo[4], mhi[4];\n')
+  w('        soda_hip_plan_margins(plan, iterate, mlo, mhi);\n')
+  w('        const int64_t es = in->elem_size;\n')
+  w('        const int64_t x0 = mlo[0], x1 = in->extent[0] - mhi[0];\n')
+  w('        const int64_t inner_rows = row_bytes / (in->extent[0] * es);\n')
+  w('        for (int64_t y = slab.own_first; !rc && x1 > x0 && y < slab.own_last; ++y) {\n')
+  w('          if (y < mlo[last] || y >= rows - mhi[last]) continue;\n')
+  w('          for (int64_t q = 0; q < inner_rows; ++q) {\n')
+  if dim == 3:
+    w('            if (q < mlo[1] || q >= in->extent[1] - mhi[1]) continue;\n')
+  w('            const size_t off = (size_t)(q * in->extent[0] + x0) * es;\n')
+  w('            memcpy(out->host + y * row_bytes + off, stage.data() + '
+    '(y - slab.own_first) * row_bytes + off, (size_t)(x1 - x0) * es);\n')
+  w('          }\n        }\n      }\n    }\n')
+  w('    if (rc) fprintf(*error_report, "ERROR: GPU %d: %s: %s\\n", rank, '
+    'soda_hip_error_name(rc), soda_hip_last_error());\n')
+  w('    soda_hip_free(a); soda_hip_free(b); soda_hip_free(c);\n')
+  w('    soda_hip_plan_destroy(plan);\n    soda_hip_module_unload(module);\n')
+  w('  };\n')
+  w('  std::vector<std::thread> threads;\n')
+  w('  for (int r = 0; r < ngpu; ++r) threads.emplace_back(worker, r);\n')
+  w('  for (auto& t : threads) t.join();\n')
+  w('  for (ncclComm_t comm : comms) if (comm) ncclCommDestroy(comm);\n')
+  w('  for (int rc : status) if (rc) return rc;\n')
+  w('  return 0;\n}\n#endif  // SODA_HIP_MULTI_GPU\n\n')
+
+
 def print_code(spec, kernels, out, lowered=None):
   """`spec`: the source program (golden loops, entry points); `lowered`: the
   program the kernels were generated from (descriptor literals)."""
@@ -221,13 +324,13 @@ def print_code(spec, kernels, out, lowered=None):
     w('  snprintf(k[%d].name, sizeof k[%d].name, "%s"); k[%d].kind = %s; '
       'k[%d].depth = %d; k[%d].stage = %d; k[%d].fill_rows = %d; '
       'k[%d].origin_align = %d; k[%d].min_extent[0] = %d; k[%d].min_extent[1] = %d; '
-      'k[%d].step_valu = %d; k[%d].step_bytes = %d;\n' % (
+      'k[%d].step_valu = %d; k[%d].step_bytes = %d; k[%d].xcd_tiles = %d;\n' % (
           i, i, kd['name'], i,
           'SODA_HIP_KERNEL_FUSED' if kd['kind'] == 'fused' else 'SODA_HIP_KERNEL_STAGE',
           i, kd['depth'], i, kd['stage'], i, kd.get('fill_rows', 0),
           i, kd.get('origin_align', 0), i, kd.get('min_extent', [0, 0])[0],
           i, kd.get('min_extent', [0, 0])[1], i, kd.get('step_valu', 0),
-          i, kd.get('step_bytes', 0)))
+          i, kd.get('step_bytes', 0), i, kd.get('xcd_tiles', 0)))
     w('  { static const int32_t b[] = %s, t[] = %s; for (int d = 0; d < 3; ++d) '
       'k[%d].block[d] = b[d]; for (int d = 0; d < 4; ++d) k[%d].tile[d] = t[d]; }\n'
       % (_array(kd['block']), _array(kd['tile']), i, i))
@@ -262,6 +365,11 @@ def print_code(spec, kernels, out, lowered=None):
   w('  return %s_iterate(%sblob, kIterate);\n}\n\n' % (
       app, ''.join('var_%s_buffer, ' % n for n in ins + outs)))
 
+  # ---- <app>_multi_gpu ---------------------------------------------------------
+  if len(ins) == 1 and len(outs) == 1:
+    print_multi_gpu(spec, w, app, ins[0], outs[0], dim, max(
+        [k['depth'] for k in kernels if k['kind'] == 'fused'] or [1]))
+
   # ---- <app>_test --------------------------------------------------------------
   print_selfcheck(spec, out)
   w('extern "C" int %s_test(const char* blob, const int dims[4]) {\n' % app)
@@ -294,8 +402,16 @@ def print_code(spec, kernels, out, lowered=None):
                                  '+'.join('dims[%d]' % d for d in range(dim)))
     w('    %s_host[%s] = %s;\n' % (n, ' + '.join(
         '%c*stride%d' % (_COORD[d], d) for d in range(dim)), value))
+  if len(ins) == 1 and len(outs) == 1:
+    w('#ifdef SODA_HIP_MULTI_GPU\n')
+    w('  const int run_rc = getenv("SODA_GPUS") ? %s_multi_gpu(&%s, &%s, blob, iterate, '
+      'atoi(getenv("SODA_GPUS"))) : %s_iterate(&%s, &%s, blob, iterate);\n'
+      % (app, ins[0], outs[0], app, ins[0], outs[0]))
+    w('#else\n')
   w('  const int run_rc = %s_iterate(%sblob, iterate);\n' % (
       app, ''.join('&%s, ' % n for n in ins + outs)))
+  if len(ins) == 1 and len(outs) == 1:
+    w('#endif\n')
   w('  if (run_rc != 0) return run_rc < 0 ? -run_rc : run_rc;\n')
   w('  double threshold = 0.00001;\n')
   w('  if (nullptr != getenv("THRESHOLD")) threshold = atof(getenv("THRESHOLD"));\n')

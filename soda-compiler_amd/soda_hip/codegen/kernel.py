@@ -72,6 +72,12 @@ PACKED_3D_LIGHT_WEIGHT = 10
 # aligned strips; blur 20, sobel2d 28, jacobi2d 5 gain)
 ALIGN_FULL_MAX_WEIGHT = 40
 
+# generator options of the fused 2-D forms that `generate` passes through:
+# those both forms understand, and those only the wave-pipelined form has
+SHARED_2D_OPTIONS = ('skip_fill', 'vgpr_budget', 'max_period', 'align', 'waves_per_eu')
+WP_ONLY_OPTIONS = ('pairs', 'ring', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store',
+                   'prio', 'rotate')
+
 HIPCC_FLAGS = ['-x', 'hip', '--offload-arch=gfx950', '--cuda-device-only',
                '--no-gpu-bundle-output', '-O3', '-ffp-contract=off',
                '-fno-slp-vectorize', '-fwrapv', '-std=c++17']
@@ -108,8 +114,8 @@ def extra_flags(spec):
   -O0 and -amdgpu-dpp-combine=false are correct in both cases.  Float32
   add/sub/mul with a DPP operand is verified bit-exact and the fusion is worth
   ~10 % on the jacobi kernels, so float32-only programs keep the pass."""
-  tuning = os.environ.get('SODA_HIP_TUNE_FLAGS', '').split()   # experiments only
-  if not tuning and spec['dim'] == 2 and \
+  tuning = []
+  if spec['dim'] == 2 and \
       kernel_stream2d_wp.packable(specmod.inline_pointwise(spec)):
     # The packed kernels run at a register cap under which the default scheduler
     # serialises whole level-rows on one accumulator pair; the ILP-first strategy
@@ -255,8 +261,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
         try:
           single = kernel_stream2d.emit(
               spec, depth, **common,
-              **{k: v for k, v in fused_options.items()
-                 if k not in ('pairs', 'ring', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store', 'prio', 'rotate')})
+              **{k: v for k, v in fused_options.items() if k not in WP_ONLY_OPTIONS})
         except kernel_stream2d.NotFusable as e:
           notes.append('depth %d not fused: %s' % (depth, e))
       want_piped = depth >= WAVE_PIPELINE_MIN_DEPTH and (
@@ -265,8 +270,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
               (depth >= PACKED_FROM_DEPTH and kernel_stream2d_wp.packable(spec)))))
       if want_piped:
         options = {k: v for k, v in fused_options.items()
-                   if k in ('skip_fill', 'vgpr_budget', 'max_period', 'pairs', 'align',
-                            'ring', 'waves_per_eu', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store', 'prio', 'rotate')}
+                   if k in SHARED_2D_OPTIONS + WP_ONLY_OPTIONS}
         if groups == -1:
           options.setdefault('vgpr_budget', AUTO_WP_BUDGET)
           lane_bytes = common['cols'] * specmod.ELEM_SIZE[spec['inputs'][0]['c_type']]
@@ -317,8 +321,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
             try:
               single = kernel_stream2d.emit(
                   spec, depth, **common,
-                  **{k: v for k, v in fused_options.items()
-                 if k not in ('pairs', 'ring', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store', 'prio', 'rotate')})
+                  **{k: v for k, v in fused_options.items() if k not in WP_ONLY_OPTIONS})
             except kernel_stream2d.NotFusable as e2:
               notes.append('depth %d not fused: %s' % (depth, e2))
       if piped is None and single is None:
@@ -358,7 +361,8 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
         options = {k[3:]: v for k, v in fused_options.items()
                    if k in ('wp_rows', 'wp_groups', 'wp_prefetch', 'wp_vgpr_budget', 'wp_split',
                            'wp_lds_budget', 'wp_waves_per_eu', 'wp_loader', 'wp_sched_fence',
-                           'wp_ring_prefetch', 'wp_pairs', 'wp_xcd_remap', 'wp_prio')}
+                           'wp_ring_prefetch', 'wp_pairs', 'wp_xcd_remap', 'wp_prio',
+                           'wp_xcd_tiles', 'wp_buffer_io')}
         options.setdefault('groups', min(depth * len(spec['stages']), 4))
         if options.get('split', 2) == 2 and not options.get('loader') and \
             options.get('rows', 16) % 2 == 0 and kernel_stream2d_wp.packable(spec):

@@ -36,13 +36,16 @@ from .kernel_common import builtin_type, device_expr, tensor_index
 from .kernel_stream2d import LANES, Instance, NotFusable, geometry, kernel_name
 
 
-def build_groups(spec, depth, prefetch, groups, loader=False, split=None, sync=1):
+def build_groups(spec, depth, prefetch, groups, loader=False, split=None, sync=1,
+                 ring_lag=1):
   """Stage instances of `depth` iterations cut into `groups` wavefronts; the
   streamed dimension is the last one (rows in 2-D, planes in 3-D).
 
   loader=True: the program input does not come through the registers of group
   0 but through an LDS ring that a separate loader wavefront fills (role
-  'ring_in' of the copy that group 0 reads, one step behind the ring)."""
+  'ring_in' of the copy that group 0 reads, `ring_lag` steps behind the ring: 1
+  when another wavefront fills it and a barrier lies in between, 0 when group 0
+  fills the ring itself)."""
   axis = spec['dim'] - 1
   if len(spec['outputs']) != 1 or len(spec['inputs']) != 1:
     raise NotFusable('one input, one output')
@@ -119,7 +122,7 @@ def build_groups(spec, depth, prefetch, groups, loader=False, split=None, sync=1
     lag = None
     for src, rel, _ in inst.reads:
       if src.role in ('lds_in', 'ring_in'):
-        src.lag = src.origin.lag + (sync if src.role == 'lds_in' else 1)
+        src.lag = src.origin.lag + (sync if src.role == 'lds_in' else ring_lag)
       v = src.lag + rel[axis] + (prefetch if src is source else 0)
       lag = v if lag is None else max(lag, v)
     inst.lag = lag

@@ -29,7 +29,7 @@ from .kernel_stream3d import kernel_name
 def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
          max_period=12, vgpr_budget=200, lds_budget=64 * 1024, split=2,
          waves_per_eu=3, loader=0, ring_prefetch=2, sched_fence=1, pairs=0,
-         xcd_remap=0, prio='3'):
+         xcd_remap=0, prio='3', xcd_tiles=1, buffer_io=1):
   """Returns (text, kernel table entry).
 
   split=2: the wavefront is a 32 x 2 grid of lanes; lane (lx, ly) holds columns
@@ -59,6 +59,30 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   the halves of R/2 pairs and the last one gathers them again (register moves
   only there); hand-offs keep the pair layout (16 bytes per lane and pair-row).
 
+  buffer_io=1 (default, two row blocks, 4- or 8- or 16-byte lanes): the plane
+  tiles are loaded and stored with raw buffer instructions on a per-plane
+  resource (base = the plane, in SGPRs; row offset = an SGPR; lane offset = one
+  VGPR), so no 64-bit address is computed per row, and the stores need no
+  branches: a lane that must not store a row gets an offset beyond the resource
+  and the hardware drops the access.  Before, the storing wavefront spent 346
+  VALU + 270 SALU instructions and ~100 branches per plane (row and column
+  predicates as exec-mask regions) against 230 VALU in the wavefronts between -
+  and every wavefront of the workgroup waits for the slowest at the barrier.
+
+  xcd_tiles=1 (default): XCD-aware placement.  Workgroups are dealt round-robin
+  over the 8 XCDs (ids b and b + 8 share one XCD and its L2), so under the plain
+  3-D grid the tiles that read each other's halo sit on DIFFERENT XCDs and every
+  halo cell - and every 128-byte line a 64-float row shares with the next tile -
+  is fetched from HBM twice: the PMC read bytes of jacobi3d were 2.5x the written
+  ones (tile halo 1.52 x line sharing 1.34 x z-chunk fill).  Here the grid is 1-D
+  and the launcher cuts the plane of tiles into super-tiles of SX x SY tiles
+  (param[1]); super-tile g goes to XCD g mod 8 and its tiles are CONSECUTIVE
+  workgroups of that XCD, hence resident together and streaming the same planes
+  at the same time: what one fetches, its neighbours find in L2.  Placement only:
+  any placement gives the same results (MI355X_MICROARCH.md: dispatch order is not
+  a contract).  Every XCD gets the same number of super-tiles; tiles beyond the
+  grid's edge exit at once.
+
   xcd_remap=1 (off): workgroups re-dealt so that each XCD (own L2) works on a
   contiguous run of tiles.  Measured on MI355X: jacobi3d 512^3 -1.5 % per launch,
   heat3d +6 %, cfg5 (box shrinking to 112^3) +12 % - the runs unbalance the XCDs
@@ -83,11 +107,17 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   if elem != 4:
     raise NotFusable('the wave-pipelined 3-D form handles 4-byte elements')
   C, R = cols, rows
+  BUF_SUFFIX = {4: 'b32', 8: 'b64', 16: 'b128'}.get(C * elem)
+  BUF_TYPE = {4: 'unsigned', 8: 'soda_u2', 16: 'soda_u4'}.get(C * elem)
+  if BUF_SUFFIX is None:
+    buffer_io = 0
   if split not in (1, 2):
     raise NotFusable('split: 1 or 2 row blocks per wavefront')
   LX = LANES // split          # lanes along x
   TR = split * R               # tile rows
-  loader = 1 if (loader and split == 2) else 0
+  loader = int(loader) if (loader and split == 2) else 0
+  self_load = loader == 2        # the first compute wavefront fills the ring itself
+  extra = 1 if loader == 1 else 0          # a wavefront that only loads
   pairs = int(bool(pairs))
   if pairs and (split != 2 or R % 2 or loader or C * 2 * elem != 16):
     raise NotFusable('packed 3-D form: two row blocks, even R, 2 columns, no loader')
@@ -101,9 +131,12 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
       return '%s[%d][%d][%d][%d]' % (ident, s, r % RP, c, r // RP)
     return '%s[%d][%d][%d]' % (ident, s, r, c)
   PF = ring_prefetch
-  RS = PF + 2                  # ring slots: PF in flight, one being read, one free
+  # ring slots: PF in flight, one being read; one more free when another wavefront
+  # fills the ring (it runs a barrier interval ahead)
+  RS = PF + (1 if self_load else 2)
   everything, per_wave, final = build_groups(spec, depth, prefetch, groups,
-                                             loader=bool(loader))
+                                             loader=bool(loader),
+                                             ring_lag=0 if self_load else 1)
   margins = specmod.iteration_margins(spec, depth)
   lo, hi = margins[-1]
   halo_lo = -(-lo[0] // C) * C
@@ -181,6 +214,9 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
        % (T_in, vec, C, elem))
   line('typedef %s %s_lds __attribute__((ext_vector_type(%d), aligned(%d)));'
        % (T_in, vec, C, C * elem))
+  if buffer_io:
+    line('typedef unsigned soda_u2 __attribute__((ext_vector_type(2)));')
+    line('typedef unsigned soda_u4 __attribute__((ext_vector_type(4)));')
 
   def slot(inst, u, back):
     return (u - back) % inst.keep
@@ -238,6 +274,28 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   def row_inside(r):
     return '' if split == 1 else ' && yt + %d >= 0 && yt + %d < H' % (r, r)
 
+  if loader:
+    # LDS-direct loads: lane l moves 16 bytes, an instruction 1 KiB = a few tile
+    # rows; nothing comes back to registers
+    rows_per_load = LANES * 16 // (LX * C * elem)
+    loads = TR // rows_per_load
+    per_row = LX * C * elem // 16
+
+  def ring_load(slot_expr, plane_expr, indent='      '):
+    line(indent + '{ i64 zz = %s; if (zz > D - 1) zz = D - 1;' % plane_expr)
+    line(indent + '  const %s* p = g_in + zz * plane + dma_lane;' % T_in)
+    for i in range(loads):
+      line(indent + '  __builtin_amdgcn_global_load_lds((const __attribute__(('
+           'address_space(1))) void*)(p + %d * W), (__attribute__((address_space(3)))'
+           ' void*)&in_ring[%s][%d][0], 16, 0, 0);' % (i * rows_per_load, slot_expr,
+                                                      i * rows_per_load))
+    line(indent + '}')
+
+  def vmcnt(n):   # s_waitcnt vmcnt(N) only (expcnt and lgkmcnt left at their maxima)
+    return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14)
+
+  barrier = 'soda_lds_barrier' if self_load else 'soda_block_barrier'
+
   def emit_body(mine):
     for u in range(period):
       line('      {  // unrolled step %d' % u)
@@ -247,7 +305,16 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
           line('        { i64 zz = head + %d; if (zz > D - 1) zz = D - 1;' % u)
           line('          const %s* p = g_in + zz * plane;' % T_in)
           line('          if (INTERIOR) {')
+          if buffer_io and split == 2:
+            line('            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_'
+                 'buffer_rsrc((void*)p, 0, (int)plane_bytes, 0x27000);')
           for r in range(R):
+            if buffer_io and split == 2:
+              line('            { const %s v = __builtin_bit_cast(%s, __builtin_amdgcn_raw_'
+                   'buffer_load_%s(rs, lane_byte, (unsigned)(%d * W * %d), 0));%s }' % (
+                       vec, vec, BUF_SUFFIX, r, elem, ''.join(' %s = v[%d];' % (
+                           cell(inst.ident, s, r, c), c) for c in range(C))))
+              continue
             address = '(p + %s + x)' % row_off(r) if split == 1 else \
                 '((const char*)(p + %d * W) + lane_byte)' % r
             line('            { const %s v = *(const %s*)%s;%s }' % (
@@ -264,6 +331,18 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
             # keep this plane's loads where they are: the scheduler otherwise
             # hoists the NEXT planes' loads above them into fresh registers
             line('          __builtin_amdgcn_sched_barrier(0);')
+          continue
+        if inst.role == 'ring_in' and self_load:
+          s = slot(inst, u, 0)
+          # this wavefront keeps PF planes in flight: issue plane head+u+PF, wait
+          # for exactly plane head+u (issued PF steps ago), read its rows back
+          ring_load('%d' % ((u + PF) % RS), 'head + %d' % (u + PF), '        ')
+          line('        __builtin_amdgcn_s_waitcnt(%d);  // vmcnt(%d)'
+               % (vmcnt(PF * loads), PF * loads))
+          line('        soda_ring_read_%s(&in_ring[%d][ly * %d][(lane & %d) * %d], %s);'
+               % (name, u % RS, R, LX - 1, C, ', '.join(
+                   '%s[%d][%d][%d]' % (inst.ident, s, r, c)
+                   for r in range(R) for c in range(C))))
           continue
         if inst.role == 'ring_in':
           s = slot(inst, u, 0)
@@ -374,7 +453,36 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
             line('        { %s_lds v;%s *(%s_lds*)&handoff[%d][%d][%d][lane * %d] = v; }'
                  % (vec, ''.join(' v[%d] = %s[%d];' % (c, src_row, c)
                                  for c in range(C)), vec, inst.handoff, u % 2, r, C))
-        if inst.final:
+        if inst.final and buffer_io and split == 2:
+          def out(r, c):
+            return 'out_tile[%d][%d][%d]' % (r % RP, c, r // RP) if pairs else \
+                'out_tile[%d][%d]' % (r, c)
+          line('        { const i64 z = head + %d;' % (u - L))
+          line('          if (z >= z0 && z < z1) {')
+          line('            %s* q = g_out + z * plane;' % T_out)
+          line('            if (!st_ragged) {')
+          line('              const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_'
+               'buffer_rsrc(q, 0, (int)plane_bytes, 0x27000);')
+          for r in range(R):
+            line('              { %s v;%s __builtin_amdgcn_raw_buffer_store_%s('
+                 '__builtin_bit_cast(%s, v), rs, (st_rows >> %d) & 1u ? lane_byte : '
+                 '0xfffffff0u, (unsigned)(%d * W * %d), 0); }' % (
+                     vec, ''.join(' v[%d] = %s;' % (c, out(r, c)) for c in range(C)),
+                     BUF_SUFFIX, BUF_TYPE, r, r, elem))
+          line('            } else {')
+          for r in range(R):
+            line('            if (%d >= st_r0 && %d < st_r1) {' % (r, r))
+            line('              if (st_full) { %s v;%s *(%s*)((char*)(q + %d * W) + '
+                 'lane_byte) = v; }' % (
+                     vec, ''.join(' v[%d] = %s;' % (c, out(r, c))
+                                  for c in range(C)), vec, r))
+            line('              else {%s }' % ''.join(
+                ' if (st_col%d) q[%s + x + %d] = %s;'
+                % (c, row_off(r), c, out(r, c)) for c in range(C)))
+            line('            }')
+          line('            }')
+          line('          } }')
+        elif inst.final:
           line('        { const i64 z = head + %d;' % (u - L))
           line('          if (z >= z0 && z < z1) {')
           line('            %s* q = g_out + z * plane;' % T_out)
@@ -406,7 +514,28 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
               line('            }')
           line('          } }')
       line('      }')
-      line('      soda_block_barrier();')
+      line('      %s();' % barrier)
+
+  if self_load:
+    # all rows of a lane's plane tile from the ring in one burst of reads the
+    # compiler does not see as LDS reads (it would wait for ALL LDS-direct loads
+    # in front of a visible one, kernel_common: soda_lds_read_f4)
+    width = {8: 'b64', 16: 'b128'}.get(C * elem)
+    if width is None:
+      raise NotFusable('self-loading ring: 8- or 16-byte lanes')
+    line('typedef %s %s_row __attribute__((ext_vector_type(%d)));' % (T_in, vec, C))
+    line('DEV void soda_ring_read_%s(const void* base, %s) {' % (
+        name, ', '.join('%s& v%d_%d' % (T_in, r, c) for r in range(R) for c in range(C))))
+    line('  %s;' % '; '.join('%s_row t%d' % (vec, r) for r in range(R)))
+    line('  asm volatile(%s' % ''.join(
+        '"ds_read_%s %%%d, %%%d offset:%d\\n\\t"\n               ' % (
+            width, r, R, r * LX * C * elem) for r in range(R)))
+    line('               "s_waitcnt lgkmcnt(0)"')
+    line('               : %s' % ', '.join('"=&v"(t%d)' % r for r in range(R)))
+    line('               : "v"((unsigned)(unsigned long long)base) : "memory");')
+    for r in range(R):
+      line('  ' + ' '.join('v%d_%d = t%d[%d];' % (r, c, r, c) for c in range(C)))
+    line('}')
 
   line('template <bool INTERIOR>')
   line('DEV void %s_tile(const soda_hip_args& a, const i64 xs, const i64 x, '
@@ -444,6 +573,17 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
       line('  const bool st_col%d = x + %d >= st_lo && x + %d < st_hi;' % (c, c, c))
     line('  (void)ly; (void)st_r0; (void)st_r1; (void)st_full;%s'
          % ''.join(' (void)st_col%d;' % c for c in range(C)))
+    if buffer_io:
+      # rows this lane stores, as a bit mask (empty when the lane's columns are
+      # not all inside the strip's store range); ragged = some lane straddles an
+      # edge of the range: such a tile takes the predicated path
+      line('  unsigned st_rows = 0;')
+      line('  for (int r = 0; r < %d; ++r) if (st_full && r >= st_r0 && r < st_r1) '
+           'st_rows |= 1u << r;' % R)
+      line('  const bool st_ragged = __builtin_amdgcn_ballot_w64(!st_full && (%s)) != 0;'
+           % ' || '.join('st_col%d' % c for c in range(C)))
+      line('  const i64 plane_bytes = W * H * %d; (void)plane_bytes; (void)st_rows; '
+           '(void)st_ragged;' % elem)
   line('  const %s* __restrict__ g_in = (const %s*)a.tensor[%d];'
        % (T_in, T_in, index[spec['inputs'][0]['name']]))
   line('  %s* __restrict__ g_out = (%s*)a.tensor[%d];' % (T_out, T_out,
@@ -451,24 +591,9 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   line('  (void)g_in; (void)g_out; (void)st_lo; (void)st_hi; (void)W; (void)D; '
        '(void)H; (void)plane; (void)wx; (void)wy; (void)in_ring;')
   line('  const i64 steps = (z1 - z0) + %d;' % (L + lo[2]))
-  if loader:
-    # The loader wavefront: lane l moves 16 bytes, an instruction 1 KiB = %d
-    # tile rows; %d instructions per plane tile, nothing comes back to registers.
-    rows_per_load = LANES * 16 // (LX * C * elem)
-    loads = TR // rows_per_load
-    per_row = LX * C * elem // 16
-    def ring_load(slot_expr, plane_expr):
-      line('      { i64 zz = %s; if (zz > D - 1) zz = D - 1;' % plane_expr)
-      line('        const %s* p = g_in + zz * plane + dma_lane;' % T_in)
-      for i in range(loads):
-        line('        __builtin_amdgcn_global_load_lds((const __attribute__(('
-             'address_space(1))) void*)(p + %d * W), (__attribute__((address_space(3)))'
-             ' void*)&in_ring[%s][%d][0], 16, 0, 0);' % (i * rows_per_load, slot_expr,
-                                                        i * rows_per_load))
-      line('      }')
-    # s_waitcnt vmcnt(N) only (expcnt and lgkmcnt left at their maxima)
-    def vmcnt(n):
-      return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14)
+  if extra:
+    # The loader wavefront: %d instructions per plane tile, nothing comes back to
+    # registers.
     line('  if (wave == 0) {')
     line('    const i64 dma_lane = (wy + (lane / %d)) * W + wx + (lane %% %d) * %d;'
          % (per_row, per_row, 16 // elem))
@@ -491,8 +616,8 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
          % vmcnt(0))
     line('  }')
   for g, mine in enumerate(per_wave):
-    line('  %sif (wave == %d) {' % ('' if g == 0 and not loader else 'else ',
-                                   g + loader))
+    line('  %sif (wave == %d) {' % ('' if g == 0 and not extra else 'else ',
+                                   g + extra))
     levels = ([int(v) for v in (prio if isinstance(prio, (list, tuple)) else str(prio).split('/'))] + [0] * groups)[:groups]
     # issue priority per wavefront, as in kernel_stream2d_wp (first one raised:
     # heat3d 380 -> 374 us per launch, cfg5 6.77 -> 6.67 ms)
@@ -508,9 +633,17 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
                 inst.ident, k, r, c, 'pk2{0.0f, 0.0f}' if pairs else '0')
                                    for c in range(C)))
     line('    i64 head = z0 - %d;' % lo[2])
+    if self_load and g == 0:      # the first PF planes of the ring
+      line('    const i64 dma_lane = (wy + (lane / %d)) * W + wx + (lane %% %d) * %d;'
+           % (per_row, per_row, 16 // elem))
+      for k in range(PF):
+        ring_load('%d' % k, 'head + %d' % k, '    ')
     line('    for (i64 n = 0; n < steps; n += %d, head += %d) {' % (period, period))
     emit_body(mine)
     line('    }')
+    if self_load and g == 0:
+      line('    __builtin_amdgcn_s_waitcnt(%d);  // no load may outlive the LDS'
+           % vmcnt(0))
     line('  }')
   line('}')
   line('')
@@ -519,7 +652,7 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
     occupancy = ' __attribute__((amdgpu_waves_per_eu(%d, %d)))' % (waves_per_eu,
                                                                    waves_per_eu)
   line('GLOBAL WG_SIZE(%d)%s void %s(soda_hip_args a) {'
-       % ((groups + loader) * LANES, occupancy, name))
+       % ((groups + extra) * LANES, occupancy, name))
   line('  __attribute__((shared)) %s handoff[%d][2][%d][%d];' % (
       T_in, max(1, groups - 1), RP, LANES * C * (2 if pairs else 1)))
   line('  __attribute__((shared)) %s in_ring[%d][%d][%d];' % (
@@ -527,13 +660,26 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   line('  const int lane = lane_id();')
   line('  const int wave = __builtin_amdgcn_readfirstlane('
        '__builtin_amdgcn_workitem_id_x() >> 6);')
-  if xcd_remap:
+  if xcd_tiles:
+    # 1-D grid; L = 8 * i + c is the i-th workgroup of XCD c (round-robin deal).
+    # The XCD's j-th super-tile (j = i / S) is global super-tile 8 j + c.
+    line('  const unsigned L = __builtin_amdgcn_workgroup_id_x();')
+    line('  const unsigned SX = (unsigned)a.param[1] & 0xffffu, '
+         'SY = (unsigned)a.param[1] >> 16;')
+    line('  const unsigned nsx = (unsigned)a.param[2] & 0xffffu, '
+         'nsy = (unsigned)a.param[2] >> 16;')
+    line('  const unsigned S = SX * SY, i = L >> 3, g = (i / S) * 8u + (L & 7u), '
+         'within = i % S;')
+    line('  const unsigned block_x = (g % nsx) * SX + within % SX;')
+    line('  const unsigned block_y = ((g / nsx) % nsy) * SY + within / SX;')
+    line('  const unsigned block_z = g / (nsx * nsy);')
+  elif xcd_remap:
     # workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an
     # L2): re-deal them so that every XCD works on a contiguous run of tiles (x
     # fastest, then y, then the z chunk) and neighbouring tiles, which read each
     # other's halo, share an L2.  Any placement is correct; bijective.
     line('  const unsigned gx = __builtin_amdgcn_grid_size_x() / %d;'
-         % ((groups + loader) * LANES))
+         % ((groups + extra) * LANES))
     line('  const unsigned gy = __builtin_amdgcn_grid_size_y();')
     line('  const unsigned total = gx * gy * __builtin_amdgcn_grid_size_z();')
     line('  const unsigned lin = __builtin_amdgcn_workgroup_id_x() + gx * ('
@@ -553,6 +699,8 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
   line('  const i64 yb = a.box_lo[1] + (i64)block_y * %d - %d;' % (r_out, y_lo))
   line('  const i64 chunk = a.param[0] > 0 ? a.param[0] : %d;' % chunk_planes)
   line('  const i64 z0 = a.box_lo[2] + (i64)block_z * chunk;')
+  if xcd_tiles:   # padding tiles of the last super-tiles
+    line('  if (yb + %d >= a.box_hi[1] || z0 >= a.box_hi[2]) return;' % y_lo)
   line('  const i64 z1 = z0 + chunk < a.box_hi[2] ? z0 + chunk : a.box_hi[2];')
   if split == 1:
     line('  const i64 x = xs - %d + lane * %d;' % (halo_lo, C))
@@ -579,11 +727,11 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
          % name)
   line('}')
   entry = dict(name=name, kind='fused', depth=depth, stage=-1,
-               block=[(groups + loader) * LANES, 1, 1],
+               block=[(groups + extra) * LANES, 1, 1],
                tile=[w_out, r_out, chunk_planes, 1], origin_align=C,
                fill_rows=L + lo[2], cols=C, rows=R, prefetch=prefetch,
                period=period, est_vgprs=est_vgprs, w_out=w_out, r_out=r_out,
                groups=groups, lds_bytes=lds_bytes, split=split, loader=loader,
-               pairs=pairs,
+               pairs=pairs, xcd_tiles=int(bool(xcd_tiles)), buffer_io=int(bool(buffer_io)),
                min_extent=[LX * C, TR] if split == 2 else [0, 0])
   return '\n'.join(o) + '\n', entry

@@ -43,7 +43,16 @@ class KernelDesc(ctypes.Structure):
               ('block', ctypes.c_int32 * 3), ('tile', ctypes.c_int32 * MAX_DIMS),
               ('fill_rows', ctypes.c_int32), ('origin_align', ctypes.c_int32),
               ('min_extent', ctypes.c_int32 * 2),
-              ('step_valu', ctypes.c_int32), ('step_bytes', ctypes.c_int32)]
+              ('step_valu', ctypes.c_int32), ('step_bytes', ctypes.c_int32),
+              ('xcd_tiles', ctypes.c_int32)]
+
+
+class Slab(ctypes.Structure):
+  _fields_ = [('rank', ctypes.c_int32), ('world', ctypes.c_int32),
+              ('reach_lo', ctypes.c_int32), ('reach_hi', ctypes.c_int32),
+              ('exchange', ctypes.c_int32),
+              ('dims', ctypes.c_int64 * MAX_DIMS),
+              ('own_first', ctypes.c_int64), ('own_last', ctypes.c_int64)]
 
 
 class Timing(ctypes.Structure):
@@ -110,6 +119,11 @@ SIGNATURES = {
     'soda_hip_sweep_timed': (ctypes.c_int, [_VP, _VPP, _VPP, _I64P, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, _VP,
                                             ctypes.POINTER(Timing)]),
+    'soda_hip_slab_extent': (ctypes.c_int, [_VP, ctypes.POINTER(Slab), _I64P, _I64P,
+                                            _I64P]),
+    'soda_hip_run_slab': (ctypes.c_int, [_VP, ctypes.POINTER(Slab), _VP, _VP, _VP, _VP,
+                                         ctypes.c_int, _VP, _VPP,
+                                         ctypes.POINTER(ctypes.c_int)]),
     'soda_hip_run_buffers': (ctypes.c_int, [_VP,
                                             ctypes.POINTER(ctypes.POINTER(BufferT)),
                                             ctypes.POINTER(ctypes.POINTER(BufferT)),

@@ -99,11 +99,11 @@ class Blob:
 
   @classmethod
   def from_source(cls, text, arch=None, options=('-fno-slp-vectorize', '-fwrapv')):
+    """`options` are part of the numerical contract (no SLP packing, wrapping
+    signed overflow) together with the flags recorded in the kernel text; there
+    is no environment override - experiments pass their own `options`."""
     from ..codegen.kernel import flags_from_text
     options = tuple(options) + tuple(flags_from_text(text))
-    if os.environ.get('SODA_HIP_SLP'):      # tuning: let the SLP vectoriser pack
-      options = tuple(o for o in options if o != '-fno-slp-vectorize')
-    options += tuple(os.environ.get('SODA_HIP_EXTRA_FLAGS', '').split())   # tuning
     h = ctypes.c_void_p()
     opts = (ctypes.c_char_p * len(options))(*[o.encode() for o in options])
     capi.check(capi.lib().soda_hip_module_compile(
@@ -186,6 +186,7 @@ def kernel_descs(table):
       d.min_extent[i] = v
     d.step_valu = int(k.get('step_valu', 0))
     d.step_bytes = int(k.get('step_bytes', 0))
+    d.xcd_tiles = int(k.get('xcd_tiles', 0))
   return arr
 
 

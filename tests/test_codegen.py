@@ -382,3 +382,43 @@ def test_parser_integer_forms():
     assert _Parser(text).c_int() == value
   with pytest.raises(Exception):
     _Parser('1.5').c_int()
+
+
+@pytest.mark.parametrize('body', [
+    'o(0, 0) = a(1, 0) + a(2, 0) + a(0, 1)',          # dx range 1..2 excludes 0
+    'o(0, 0) = a(-2, 0) + a(-1, 0)',                   # dx range -2..-1
+    'o(0, 0) = a(0, 0) + a(3, 1) * 2.0f - a(-1, -1)',
+])
+def test_one_sided_windows_keep_register_rows_in_bounds(body, tmp_path):
+  """Per-stage kernels keep a register row per (tensor, outer offset) whose range
+  always covers dx = 0 (the V-wide centre load lands there): a window that lies
+  on one side of the store point must not index outside that row.  Compiled with
+  -Werror=array-bounds so that a regression is a build failure, not UB."""
+  text = ('kernel: onesided\nburst width: 512\nunroll factor: 2\niterate: 1\n'
+          'input float: a(32, *)\noutput float: %s\n' % body)
+  spec = specmod.spec_from_stencil(frontend.loads(text))
+  src, table = kernel.generate(spec)
+  assert 'r0[-' not in src
+  out = tmp_path / 'onesided.hsaco'
+  kernel.compile_to_code_object(src, str(out), extra_flags=['-Werror=array-bounds'])
+  assert out.stat().st_size > 1000
+
+
+def test_generated_cpp_host_multi_gpu_entry_compiles(tmp_path):
+  """The generated C++ host with -DSODA_HIP_MULTI_GPU (`<app>_multi_gpu`: one
+  thread per GPU, ncclCommInitAll, soda_hip_run_slab) is valid C++ against
+  include/soda_hip.h and the RCCL header."""
+  src = tmp_path / 'jacobi3d_host.cpp'
+  r = run_sodac(os.path.join(SAMPLES, 'jacobi3d.soda'), '--hip-host-cpp', str(src))
+  assert r.returncode == 0, r.stderr
+  text = src.read_text()
+  assert 'extern "C" int jacobi3d_multi_gpu(' in text and 'soda_hip_run_slab(' in text
+  subprocess.check_call(['g++', '-std=c++17', '-fsyntax-only', '-fopenmp',
+                         '-DSODA_HIP_MAIN', '-DSODA_HIP_MULTI_GPU',
+                         '-D__HIP_PLATFORM_AMD__', '-I', '/opt/rocm/include', '-I',
+                         os.path.join(ROOT, 'include'), str(src)])
+  # programs with several inputs have no slab entry (yet)
+  src2 = tmp_path / 'denoise2d_host.cpp'
+  assert run_sodac(os.path.join(SAMPLES, 'denoise2d.soda'), '--hip-host-cpp',
+                   str(src2)).returncode == 0
+  assert '_multi_gpu' not in src2.read_text()

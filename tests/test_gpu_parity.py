@@ -426,6 +426,88 @@ def test_generated_cpp_host_program(tmp_path, app, dims, iterate):
   assert r.returncode != 0 and 'not generated for this program' in r.stderr
 
 
+@pytest.mark.parametrize('app,dims,iterate', [
+    ('jacobi2d', [700, 400], '30'), ('heat3d', [60, 50, 40], '5')])
+def test_generated_cpp_host_multi_gpu_entry(tmp_path, app, dims, iterate):
+  """`<app>_multi_gpu` of the generated C++ host (one thread per GPU over
+  soda_hip_run_slab; -DSODA_HIP_MULTI_GPU): with the one GPU of this box the slab
+  is the whole grid and no communicator is made - the reference's self-check must
+  still say PASS.  (More than one GPU: ncclCommInitAll + ghost exchanges; that
+  path has not run on hardware.)"""
+  import subprocess
+  import sys
+  from conftest import ROOT
+  sodac = os.path.join(ROOT, 'soda-compiler_amd', 'sodac')
+  csrc = os.path.join(ROOT, 'soda-compiler_amd', 'csrc')
+  src = tmp_path / (app + '_host.cpp')
+  subprocess.check_call([sys.executable, sodac,
+                         os.path.join(ROOT, 'tests', 'samples', app + '.soda'),
+                         '--hip-host-cpp', str(src)])
+  exe = tmp_path / (app + '_host')
+  subprocess.check_call(['g++', '-std=c++17', '-O1', '-fopenmp', '-ffp-contract=off',
+                         '-DSODA_HIP_MAIN', '-DSODA_HIP_MULTI_GPU',
+                         '-D__HIP_PLATFORM_AMD__', '-I', '/opt/rocm/include',
+                         '-I', os.path.join(ROOT, 'include'), str(src), '-L', csrc,
+                         '-lsoda_hip', '-L/opt/rocm/lib', '-lrccl', '-lpthread',
+                         '-Wl,-rpath,' + csrc, '-Wl,-rpath,/opt/rocm/lib',
+                         '-o', str(exe)])
+  blob = os.path.join(gpu_util.BLOBS, app + '.hsaco')
+  r = subprocess.run([str(exe), blob] + [str(d) for d in dims], capture_output=True,
+                     text=True, env=dict(os.environ, SODA_ITERATE=iterate, SODA_GPUS='1'))
+  assert r.returncode == 0, r.stderr
+  assert 'INFO: PASS!' in r.stderr
+
+
+def test_run_slab_c_entry_with_one_rank():
+  """soda_hip_run_slab / soda_hip_slab_extent (the slab driver below Python) with
+  world = 1: same result as a plain sweep; a slab thinner than its ghost regions
+  is refused."""
+  import ctypes
+  from soda_hip.runtime import capi
+  prog = program('jacobi2d')
+  spec = prog.spec
+  (a,) = gpu_util.random_inputs(spec, (300, 900))
+  want = prog.run_numpy([a], iterate=50)[0]
+  slab = capi.Slab(rank=0, world=1, reach_lo=1, reach_hi=1, exchange=20,
+                   own_first=0, own_last=300)
+  slab.dims[0], slab.dims[1] = 900, 300
+  local = (ctypes.c_int64 * 4)()
+  glo, ghi = ctypes.c_int64(), ctypes.c_int64()
+  capi.check(capi.lib().soda_hip_slab_extent(prog.handle, ctypes.byref(slab), local,
+                                             ctypes.byref(glo), ctypes.byref(ghi)))
+  assert list(local)[:2] == [900, 300] and (glo.value, ghi.value) == (0, 0)
+  bufs = [host.DeviceArray(a.nbytes) for _ in range(3)]
+  bufs[0].upload(a)
+  for bf in bufs[1:]:
+    bf.zero()
+  result, n_ex = ctypes.c_void_p(), ctypes.c_int()
+  capi.check(capi.lib().soda_hip_run_slab(
+      prog.handle, ctypes.byref(slab), None, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, 50,
+      None, ctypes.byref(result), ctypes.byref(n_ex)))
+  capi.check(capi.lib().soda_hip_stream_synchronize(None))
+  assert n_ex.value == 0 and result.value in (bufs[1].ptr, bufs[2].ptr)
+  got = (bufs[1] if result.value == bufs[1].ptr else bufs[2]).download(a.shape, a.dtype)
+  assert np.array_equal(got[50:-50, 50:-50], want[50:-50, 50:-50])
+  # a middle rank whose ghost regions are deeper than its own rows
+  bad = capi.Slab(rank=1, world=3, reach_lo=1, reach_hi=1, exchange=200,
+                  own_first=100, own_last=200)
+  bad.dims[0], bad.dims[1] = 900, 300
+  assert capi.lib().soda_hip_slab_extent(prog.handle, ctypes.byref(bad), local, None,
+                                         None) == -8
+  mid = capi.Slab(rank=1, world=3, reach_lo=1, reach_hi=1, exchange=24,
+                  own_first=100, own_last=200)
+  mid.dims[0], mid.dims[1] = 900, 300
+  capi.check(capi.lib().soda_hip_slab_extent(prog.handle, ctypes.byref(mid), local,
+                                             ctypes.byref(glo), ctypes.byref(ghi)))
+  assert list(local)[:2] == [900, 148] and (glo.value, ghi.value) == (24, 24)
+  # world > 1 without a communicator is an error, not a crash
+  assert capi.lib().soda_hip_run_slab(prog.handle, ctypes.byref(mid), None, bufs[0].ptr,
+                                      bufs[1].ptr, bufs[2].ptr, 10, None,
+                                      ctypes.byref(result), None) == -12
+  for bf in bufs:
+    bf.free()
+
+
 def _buffer(extent=(), min_=(), host=None, elem_size=0):
   import ctypes
   from soda_hip.runtime import capi

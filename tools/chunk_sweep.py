@@ -13,6 +13,7 @@ from soda_hip import frontend  # noqa: E402
 from soda_hip.codegen import kernel, spec as specmod  # noqa: E402
 from soda_hip.runtime import host  # noqa: E402
 
+os.environ['SODA_HIP_TUNING'] = '1'      # the run-time reads chunk overrides only then
 app = sys.argv[1]
 shapes = [tuple(int(v) for v in s.split('x')) for s in sys.argv[2].split(',')]
 rng = np.random.default_rng(1)

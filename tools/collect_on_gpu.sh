@@ -1,23 +1,32 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): the rocprofv3 passes that tools/collect_profiles.py
-# turns into profiles/<tag>_*.  usage: bash tools/collect_on_gpu.sh r01
+# turns into profiles/<tag>_*.  usage: bash tools/collect_on_gpu.sh r02
+# One --kernel-trace --stats pass of the default bench, then per workload one
+# --pmc FETCH_SIZE and one --pmc WRITE_SIZE pass (separate runs: the TCC block
+# cannot count both at once, MI355X_MICROARCH.md, rocprofv3 PMC slots).
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out
-rm -rf $out/prof_$tag $out/pmc_fetch* $out/pmc_write*
+rm -rf $out/prof_$tag $out/pmc_${tag}_*
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$tag -- \
     python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 > $out/prof_${tag}_bench.log 2>&1
-grep "^{" $out/prof_${tag}_bench.log | cut -c1-400
-for c in FETCH_SIZE:fetch WRITE_SIZE:write; do
-  rocprofv3 --pmc ${c%%:*} --output-format csv -d $out/pmc_${c##*:} -- \
-      python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 > $out/pmc_${c##*:}.log 2>&1
-  echo "pmc ${c%%:*} jacobi2d done"
-  rocprofv3 --pmc ${c%%:*} --output-format csv -d $out/pmc_${c##*:}_seidel2d -- \
-      python3 bench.py --app seidel2d --iterate 100 --steps 1 --warmup 0 --cpu-seconds 0 > $out/pmc_${c##*:}_seidel2d.log 2>&1
-  rocprofv3 --pmc ${c%%:*} --output-format csv -d $out/pmc_${c##*:}_blur -- \
-      python3 bench.py --app blur --iterate 1 --steps 1 --warmup 0 --cpu-seconds 0 > $out/pmc_${c##*:}_blur.log 2>&1
-  rocprofv3 --pmc ${c%%:*} --output-format csv -d $out/pmc_${c##*:}_jacobi3d -- \
-      python3 bench.py --app jacobi3d --size 512 512 512 --iterate 200 --steps 1 --warmup 0 --cpu-seconds 0 > $out/pmc_${c##*:}_jacobi3d.log 2>&1
-  echo "pmc ${c%%:*} others done"
-done
+grep "^{" $out/prof_${tag}_bench.log | cut -c1-300
+# name|bench arguments   (the workload table tools/collect_profiles.py reads back)
+cat > $out/pmc_${tag}_workloads.txt <<'WL'
+cfg4|--app jacobi2d --size 16384 16384 --iterate 1000
+cfg2|--app jacobi2d --size 8192 8192 --iterate 100
+cfg3|--app blur --size 16384 16384 --iterate 1
+cfg5|--app jacobi3d --size 512 512 512 --iterate 200
+seidel2d|--app seidel2d --size 16384 16384 --iterate 100
+sobel2d|--app sobel2d --size 16384 16384 --iterate 1
+heat3d|--app heat3d --size 512 512 512 --iterate 20
+WL
+while IFS='|' read -r name wargs; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d $out/pmc_${tag}_${name}_$c -- \
+        python3 bench.py $wargs --steps 1 --warmup 0 --cpu-seconds 0 \
+        > $out/pmc_${tag}_${name}_$c.log 2>&1
+  done
+  echo "pmc $name done"
+done < $out/pmc_${tag}_workloads.txt

@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 output of one round (gpurun_out/) into the small files
-committed under profiles/: kernel-trace stats, HBM traffic from the PMC passes.
+"""Turns the rocprofv3 output of one round (gpurun_out/, written by
+tools/collect_on_gpu.sh) into the small files committed under profiles/:
 
-The three passes (see profiles/README.md for the exact commands):
-  rocprofv3 --kernel-trace --stats   -> <round>_kernel_stats.csv
-  rocprofv3 --pmc FETCH_SIZE         -> read bytes   (x2 on gfx950, see below)
-  rocprofv3 --pmc WRITE_SIZE         -> write bytes
-FETCH_SIZE/WRITE_SIZE are in KiB.  MI355X_MICROARCH.md (HBM section): on gfx950
-FETCH_SIZE reports exactly half the bytes of a wide coalesced streaming read, so
-it is doubled; WRITE_SIZE is exact for 16-byte-per-lane streaming stores.
+  <round>_kernel_stats.csv          --kernel-trace --stats summary of bench.py
+  <round>_bench_under_rocprof.json  the bench line printed during that pass
+  <round>_traffic.json              HBM bytes per launch from the PMC passes
+
+The traffic file holds one entry per (kernel, grid, iteration count): a figure
+measured on one grid says nothing about another, so bench.py only quotes an entry
+whose kernel AND dims AND iterate match its own run, and `commit` says which tree
+the kernels were built from.  FETCH_SIZE / WRITE_SIZE are in KiB.
+MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half the bytes of a
+coalesced streaming read, so it is doubled; WRITE_SIZE is exact.  The rule was
+re-checked for 4-, 8- and 16-byte-per-lane copies with tools/pmc_calib.hip
+(512 MiB read -> FETCH_SIZE 256 MiB in all three; profiles/r02_pmc_calibration.txt).
 """
 import collections
 import csv
@@ -16,57 +21,80 @@ import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def counter_per_kernel(folder, counter):
+  files = glob.glob(os.path.join(folder, '*', '*_counter_collection.csv'))
+  if not files:
+    return {}
+  agg = collections.defaultdict(list)
+  for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
+    if r['Counter_Name'] == counter and not r['Kernel_Name'].startswith('__amd_rocclr'):
+      agg[r['Kernel_Name']].append(float(r['Counter_Value']))
+  return agg
+
+
 def main():
-  tag = sys.argv[1]                       # e.g. r01
+  tag = sys.argv[1]                       # e.g. r02
   src = os.path.join(ROOT, 'gpurun_out')
   dst = os.path.join(ROOT, 'profiles')
   os.makedirs(dst, exist_ok=True)
-  newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)
-  stats = newest(os.path.join(src, 'prof_%s' % tag, '*', '*_kernel_stats.csv'))
-  shutil.copy(stats, os.path.join(dst, '%s_kernel_stats.csv' % tag))
-  traffic = {}
-  # pmc_fetch / pmc_write hold the passes of the default bench; pmc_fetch_<x> /
-  # pmc_write_<x> those of other workloads (kernel names are unique per program)
-  for counter, prefix in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
-    for folder in sorted(glob.glob(os.path.join(src, prefix + '*'))):
-      if not os.path.isdir(folder):
-        continue
-      f = newest(os.path.join(folder, '*', '*_counter_collection.csv'))
-      agg = collections.defaultdict(list)
-      for r in csv.DictReader(open(f)):
-        if r['Counter_Name'] == counter:
-          agg[r['Kernel_Name']].append(float(r['Counter_Value']))
-      for kernel, vals in agg.items():
-        if kernel.startswith('__amd_rocclr') and folder != os.path.join(src, prefix):
-          continue
-        traffic.setdefault(kernel, {})[counter] = dict(
-            launches=len(vals), mean_KiB=sum(vals) / len(vals), min_KiB=min(vals),
-            max_KiB=max(vals))
-  out = {}
-  for kernel, c in traffic.items():
-    if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
-      read = 2.0 * c['FETCH_SIZE']['mean_KiB'] * 1024
-      write = c['WRITE_SIZE']['mean_KiB'] * 1024
-      out[kernel] = dict(read_bytes_per_launch=read, write_bytes_per_launch=write,
-                         hbm_bytes_per_launch=read + write,
-                         fetch_size_raw_KiB=c['FETCH_SIZE']['mean_KiB'],
-                         write_size_raw_KiB=c['WRITE_SIZE']['mean_KiB'],
-                         launches=c['FETCH_SIZE']['launches'],
-                         correction='FETCH_SIZE x2 (gfx950), WRITE_SIZE x1')
+  stats = glob.glob(os.path.join(src, 'prof_%s' % tag, '*', '*_kernel_stats.csv'))
+  if stats:
+    shutil.copy(max(stats, key=os.path.getmtime),
+                os.path.join(dst, '%s_kernel_stats.csv' % tag))
+  try:
+    commit = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'],
+                                     cwd=ROOT, text=True).strip()
+    if subprocess.check_output(['git', 'status', '--porcelain', '--', 'soda-compiler_amd'],
+                               cwd=ROOT, text=True).strip():
+      commit += '+uncommitted'
+  except (OSError, subprocess.CalledProcessError):
+    commit = None
+  entries = []
+  with open(os.path.join(src, 'pmc_%s_workloads.txt' % tag)) as f:
+    workloads = [line.strip().split('|') for line in f if line.strip()]
+  for name, args in workloads:
+    words = args.split()
+    app = words[words.index('--app') + 1]
+    i = words.index('--size') + 1
+    dims = []
+    while i < len(words) and not words[i].startswith('--'):
+      dims.append(int(words[i]))
+      i += 1
+    iterate = int(words[words.index('--iterate') + 1])
+    fetch = counter_per_kernel(os.path.join(src, 'pmc_%s_%s_FETCH_SIZE' % (tag, name)),
+                               'FETCH_SIZE')
+    write = counter_per_kernel(os.path.join(src, 'pmc_%s_%s_WRITE_SIZE' % (tag, name)),
+                               'WRITE_SIZE')
+    for kernel in sorted(set(fetch) & set(write)):
+      read_b = 2.0 * sum(fetch[kernel]) / len(fetch[kernel]) * 1024
+      write_b = sum(write[kernel]) / len(write[kernel]) * 1024
+      entries.append(dict(
+          workload=name, app=app, kernel=kernel, dims=dims, iterate=iterate,
+          launches=len(fetch[kernel]), read_bytes_per_launch=read_b,
+          write_bytes_per_launch=write_b, hbm_bytes_per_launch=read_b + write_b,
+          read_over_write=read_b / write_b if write_b else None,
+          fetch_size_raw_KiB=sum(fetch[kernel]) / len(fetch[kernel]),
+          write_size_raw_KiB=sum(write[kernel]) / len(write[kernel]),
+          correction='FETCH_SIZE x2 (gfx950), WRITE_SIZE x1', commit=commit))
   with open(os.path.join(dst, '%s_traffic.json' % tag), 'w') as f:
-    json.dump(out, f, indent=1, sort_keys=True)
+    json.dump(dict(entries=entries), f, indent=1, sort_keys=True)
   p = os.path.join(src, 'prof_%s_bench.log' % tag)
   if os.path.exists(p):
     with open(p) as f:
       lines = [l for l in f if l.startswith('{"metric')]
     with open(os.path.join(dst, '%s_bench_under_rocprof.json' % tag), 'w') as f:
       f.writelines(lines)
-  print(json.dumps(out, indent=1))
+  for e in entries:
+    print('%-10s %-28s %-18s read %8.1f MB  write %8.1f MB  read/write %.2f  (%d launches)' % (
+        e['workload'], e['kernel'], 'x'.join(map(str, e['dims'])),
+        e['read_bytes_per_launch'] / 1e6, e['write_bytes_per_launch'] / 1e6,
+        e['read_over_write'], e['launches']))
 
 
 if __name__ == '__main__':
