@@ -29,9 +29,12 @@ for name, args in CASES:
   if not line:
     print(name, 'FAILED', r.stderr[-500:]); continue
   d = json.loads(line[-1]); d['case'] = name; rows.append(d)
-  print('| %s | %.3f | %.1f | %s | %.0f | %.2f | %.1f (%d thr) |' % (
-      name, d['ms_per_step'], d['value'], d['roofline']['kernel'], d['roofline']['achieved'],
-      d['roofline']['frac'], d['cpu_baseline']['value'], d['cpu_baseline']['cores']), flush=True)
+  rf = d['roofline']
+  print('| %s | %.3f | %.1f | %s | %s | %s %.2f | alg %.2f | hbm %s | valu %.2f | %.1f (%d thr) |' % (
+      name, d['ms_per_step'], d['value'], d['config']['depth_schedule'], rf['kernel'],
+      rf['bound'], rf['frac'], rf['frac_algorithmic'],
+      '%.2f' % rf['hbm_measured_frac'] if rf.get('hbm_measured_frac') else 'n/a',
+      rf['valu_frac'], d['cpu_baseline']['value'], d['cpu_baseline']['cores']), flush=True)
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 with open(os.path.join(ROOT, 'gpurun_out', '%s_all_samples.json' % tag), 'w') as f:
   json.dump(rows, f, indent=1)
