@@ -252,6 +252,7 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
                   (long long)args.dims[d]);
   for (int d = 0; d < 3; ++d) out->grid[d] = 1;
   if (dim > 3) return fail(SODA_HIP_ERR_INTERNAL, "4-D launches are not implemented");
+  bool fold_rows = false;
   for (int d = 0; d < dim; ++d) {
     int64_t extent = args.box_hi[d] - args.box_lo[d];
     if (extent <= 0) { *empty = true; return 0; }
@@ -289,14 +290,30 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
                                          step_seconds(plan, k, blocks) * 1e6;
     }
     int64_t g = (extent + tile - 1) / tile;
-    // per-stage kernels stride over rows / planes by the grid size
-    // (kernel_stage.py), so their outer grid dimensions may be clamped
-    if (d > 0 && desc.kind == SODA_HIP_KERNEL_STAGE) g = std::min<int64_t>(g, 65535);
+    if (d > 0 && desc.kind == SODA_HIP_KERNEL_STAGE && g > 65535) {
+      // Per-stage kernels take one row (plane) per workgroup; past the 65535
+      // limit of grid.y / grid.z the rows and planes are folded into one index
+      // spread over grid.y x grid.z (kernel_stage.py; param[0] = 1 tells a 3-D
+      // kernel so).  Done after the loop, once every extent is known.
+      fold_rows = true;
+      g = 1;
+    }
     if (g > (d == 0 ? 2147483647LL : 65535LL))
       return fail(SODA_HIP_ERR_EXTENTS_TOO_LARGE,
                   "grid dimension %d of kernel %s would be %lld", d, desc.name,
                   (long long)g);
     out->grid[d] = (unsigned)g;
+  }
+  if (fold_rows) {
+    int64_t rows = 1;
+    for (int d = 1; d < dim; ++d) rows *= args.box_hi[d] - args.box_lo[d];
+    const int64_t gy = 65535, gz = (rows + gy - 1) / gy;
+    if (gz > 65535)
+      return fail(SODA_HIP_ERR_EXTENTS_TOO_LARGE, "kernel %s: %lld rows", desc.name,
+                  (long long)rows);
+    out->grid[1] = (unsigned)gy;
+    out->grid[2] = (unsigned)gz;
+    out->args.param[0] = 1;
   }
   if (desc.xcd_tiles && dim == 3) {
     // XCD-aware placement (kernel_stream3d_wp.py, xcd_tiles): the plane of

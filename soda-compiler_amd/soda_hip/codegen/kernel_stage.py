@@ -60,16 +60,25 @@ def emit(spec):
              '  const i64 x = a.box_lo[0] + ((i64)__builtin_amdgcn_workgroup_id_x()'
              ' * %d + __builtin_amdgcn_workitem_id_x()) * %d;' % (BLOCK, V)]
     lines.append('  if (x >= a.box_hi[0]) return;')
-    # rows / planes: one per workgroup, strided by the grid so that extents
-    # beyond the 65535-workgroup limit of grid.y / grid.z still run (the
-    # launcher clamps the grid there)
+    # rows / planes: one per workgroup.  Boxes with more than 65535 rows or planes
+    # (the limit of grid.y / grid.z) are launched with the rows and planes folded
+    # into one index n = wgid_y + wgid_z * grid.y (param[0] = 1, soda_hip.cpp:
+    # make_launch); everything else keeps the direct mapping.
+    if dim == 2:
+      lines.append('  const i64 y = a.box_lo[1] + __builtin_amdgcn_workgroup_id_y() + '
+                   '(i64)__builtin_amdgcn_workgroup_id_z() * __builtin_amdgcn_grid_size_y();')
+      lines.append('  if (y >= a.box_hi[1]) return;')
     if dim >= 3:
-      lines.append('  for (i64 z = a.box_lo[2] + __builtin_amdgcn_workgroup_id_z(); '
-                   'z < a.box_hi[2]; z += __builtin_amdgcn_grid_size_z())')
-    if dim >= 2:
-      lines.append('  for (i64 y = a.box_lo[1] + __builtin_amdgcn_workgroup_id_y(); '
-                   'y < a.box_hi[1]; y += __builtin_amdgcn_grid_size_y())')
-    lines.append('  {')
+      lines.append('  i64 y = a.box_lo[1] + __builtin_amdgcn_workgroup_id_y();')
+      lines.append('  i64 z = a.box_lo[2] + __builtin_amdgcn_workgroup_id_z();')
+      lines.append('  if (a.param[0] == 1) {')
+      lines.append('    const i64 ey = a.box_hi[1] - a.box_lo[1];')
+      lines.append('    const i64 n = __builtin_amdgcn_workgroup_id_y() + '
+                   '(i64)__builtin_amdgcn_workgroup_id_z() * __builtin_amdgcn_grid_size_y();')
+      lines.append('    y = a.box_lo[1] + n % ey;')
+      lines.append('    z = a.box_lo[2] + n / ey;')
+      lines.append('    if (z >= a.box_hi[2]) return;')
+      lines.append('  }')
     if dim >= 2:
       lines.append('  const i64 s1 = a.dims[0];')
     if dim >= 3:
@@ -161,7 +170,6 @@ def emit(spec):
       lines.append('  }')
     else:
       lines.append('  t_out[c] = result[0];')
-    lines.append('  }')
     lines.append('}')
     out.append('\n'.join(lines))
     table.append(dict(name=name, kind='stage', depth=0, stage=index[stage['name']],

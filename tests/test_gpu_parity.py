@@ -611,6 +611,26 @@ def test_select_min_max_program():
   assert np.array_equal(got[:-1, 1:-1], want)
 
 
+def test_per_stage_kernels_beyond_the_grid_limit():
+  """More rows than grid.y holds (65535): the per-stage kernels fold the rows into
+  grid.y x grid.z instead of failing with buffer_extents_too_large; same cells as
+  the fused kernels, which stream the rows in chunks."""
+  prog = program('jacobi2d')
+  a = np.random.default_rng(12).random((70001, 72), dtype=np.float32)
+  prog.set_max_depth(-1)
+  staged = prog.run_numpy([a], iterate=2)[0]
+  prog.set_max_depth(0)
+  fused = prog.run_numpy([a], iterate=2)[0]
+  assert np.array_equal(staged, fused) and staged[2:-2, 2:-2].std() > 0
+  p3 = program('jacobi3d')
+  b = np.random.default_rng(13).random((3, 66001, 40), dtype=np.float32)
+  p3.set_max_depth(-1)
+  staged = p3.run_numpy([b], iterate=1)[0]
+  want = oracle('jacobi3d').run([b], iterate=1)['t0']
+  p3.set_max_depth(0)
+  assert np.array_equal(staged[1:-1, 1:-1, 1:-1], want[1:-1, 1:-1, 1:-1])
+
+
 def test_one_dimensional_program_jit():
   """A 1-D program (the grammar's `name(*)` form): per-stage kernels, JIT path,
   iterate 3, against the oracle."""

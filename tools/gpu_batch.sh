@@ -1,5 +1,4 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-out=gpurun_out
-( time python3 -m pytest tests -m gpu -x -q --durations=8 ) > $out/gputests_r02c.log 2>&1; tail -16 $out/gputests_r02c.log
-python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+python3 tools/ab_stage.py 2>&1 | grep "new\|old"
+python3 -m pytest tests/test_gpu_parity.py -k "beyond_the_grid or multi_output or stage or one_dim or fixture" -x -q 2>&1 | tail -3
