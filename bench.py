@@ -11,11 +11,15 @@ and neighbours exchange ghost rows over RCCL every `--exchange` iterations.
 
 Prints ONE JSON line (rank 0).  `value` = valid cell-updates / wall time, valid =
 the cells the reference semantics define (the box shrinks by the stencil radius
-every iteration); `roofline` prices the dominant kernel at
-8 algorithmic bytes per cell-update against the 8 TB/s HBM peak -- with temporal
-blocking the fraction may exceed 1, which is the point of time-tiling;
-`cpu_baseline` is the CPU oracle (a port of the loop nest the reference emits
-into `<app>_test`) timed on this host's cores on a bounded sample.
+every iteration).  `roofline` describes the dominant kernel
+(roofline_block below): `bound` names its binding physical limit - HBM traffic
+(PMC bytes of this kernel on this grid, from profiles/rNN_traffic.json) or VALU
+issue (useful f32 lane-operations against the chip's 78.6 T/s) - and `frac` the
+fraction of that limit's peak; `frac_algorithmic` is SURVEY 8(d)'s figure
+(algorithmic bytes per update / time / 8 TB/s), which temporal blocking pushes
+past 1 and which is therefore not a bound.  `cpu_baseline` is the CPU oracle (a
+port of the loop nest the reference emits into `<app>_test`) timed on this host's
+cores on a bounded sample.
 """
 import argparse
 import json
@@ -317,6 +321,10 @@ def main():
            '--master-port', os.environ.get('MASTER_PORT', '29533'),
            os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.call(cmd))
+  if args.force_dist and 'RANK' not in os.environ:      # a one-rank group by hand
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29534')
   if args.gpus > 1 or world > 1 or args.force_dist:
     from soda_hip.runtime import dist
     result = dist.bench_main(args, open_program, make_input, per_iteration_updates,

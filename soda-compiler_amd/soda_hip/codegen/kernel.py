@@ -338,11 +338,19 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
       # rows per lane: as many as the register file allows (taller tiles waste
       # less on the y halo)
       options = {k: v for k, v in fused_options.items() if not k.startswith('wp_')}
-      row_choices = [options.pop("rows")] if "rows" in options else [16, 12]
+      # (rows, columns) per lane: the tallest tile the register file allows (taller
+      # tiles waste less on the y halo).  Programs with several live tensors
+      # (denoise3d, lowered to g and output over the inputs f and u) fit with one
+      # column per lane: 12 rows (156 VGPRs, three wavefronts per SIMD) before 16
+      # (235 VGPRs, two) - denoise3d per sweep at 256^3 / 512^3: 160 / 971 us against
+      # 200 / 999 us, the two per-stage launches 165 / 1281 us
+      shapes = [(options.pop('rows'), cols or 2)] if 'rows' in options else \
+          [(16, cols or 2), (12, cols or 2)] + ([] if cols else [(12, 1), (16, 1)])
       error = None
-      for rows in row_choices:
+      for rows, lane_cols in shapes:
         try:
-          ftext, entry = kernel_stream3d.emit(spec, depth, rows=rows, **options)
+          ftext, entry = kernel_stream3d.emit(spec, depth, rows=rows, cols=lane_cols,
+                                              **options)
         except kernel_stream2d.NotFusable as e:
           error = e
           continue

@@ -1,4 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python3 tools/ab_stage.py 2>&1 | grep "new\|old"
-python3 -m pytest tests/test_gpu_parity.py -k "beyond_the_grid or multi_output or stage or one_dim or fixture" -x -q 2>&1 | tail -3
+out=gpurun_out
+for n in 256 512; do
+TUNE_HIPCC=1 python3 tools/tune3d.py denoise3d $n 1 'rows=16,cols=1' 'rows=12,cols=1' 'rows=16,cols=1,waves_per_eu=3' 'rows=8,cols=2' 'rows=8,cols=1' 'fused=0' 2>&1 | grep -v amdgpu.ids
+done
