@@ -217,8 +217,14 @@ def test_pipeline_lags_match_the_reference_reuse_model():
 
 
 def test_unfusable_programs_fall_back_to_stage_kernels():
-  # eight stages of 3-D planes do not fit the register file: per-stage kernels
+  # denoise3d (lowered to two stages over two inputs) does not fit the register
+  # file with two columns per lane; it fuses with one column and 12 rows
   text, table = kernel.generate(spec_of('denoise3d'))
+  fused = [k for k in table if k['kind'] == 'fused']
+  assert [(k['depth'], k['rows'], k['cols'], k['tile'][1]) for k in fused] == [(1, 12, 1, 8)]
+  assert len([k for k in table if k['kind'] == 'stage']) == 2
+  # the source program (eight stages, not lowered) fits no fused form at all
+  text, table = kernel.generate(spec_of('denoise3d'), inline=False)
   assert all(k['kind'] == 'stage' for k in table) and 'not fused' in text
   with pytest.raises(kernel_stream2d.NotFusable):
     kernel_stream2d.emit(spec_of('jacobi3d'), 1)
