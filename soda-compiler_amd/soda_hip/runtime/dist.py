@@ -255,8 +255,12 @@ class StreamSchedule:
   the host) wait for it."""
   overlapped = True
 
-  def __init__(self, torch):
+  def __init__(self, torch, host_sync=False):
+    """host_sync: the backend reads device memory from the host side without
+    ordering itself against streams (gloo in the one-GPU rehearsal): wait for
+    the side stream before handing it the arrays."""
     self.torch = torch
+    self.host_sync = host_sync
     self.side = torch.cuda.Stream()
     self.bands_done = torch.cuda.Event()
     self.ghosts_landed = None
@@ -274,6 +278,8 @@ class StreamSchedule:
     t1 = self.torch.cuda.Event(enable_timing=True)
     with self.torch.cuda.stream(self.side):
       t0.record()
+      if self.host_sync:
+        self.side.synchronize()
       fn()
       t1.record()
     self.spans.append((t0, t1))
@@ -293,14 +299,17 @@ class StreamSchedule:
 class TimedSerialSchedule(SerialSchedule):
   """The serial order on a GPU, with the exchanges bracketed by events."""
 
-  def __init__(self, torch):
+  def __init__(self, torch, host_sync=False):
     self.torch = torch
+    self.host_sync = host_sync
     self.spans = []
 
   def exchange(self, fn):
     t0 = self.torch.cuda.Event(enable_timing=True)
     t1 = self.torch.cuda.Event(enable_timing=True)
     t0.record()
+    if self.host_sync:
+      self.torch.cuda.current_stream().synchronize()
     fn()
     t1.record()
     self.spans.append((t0, t1))
@@ -319,9 +328,18 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
   rank = int(os.environ.get('RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
+  # SODA_DIST_BACKEND=gloo: rehearsal of the multi-rank path where the ranks
+  # share ONE GPU (RCCL refuses two ranks on a device); ghost rows then travel
+  # through the host.  Production is nccl (= RCCL over xGMI), one GPU per rank.
+  backend = os.environ.get('SODA_DIST_BACKEND', 'nccl')
+  if backend != 'nccl':
+    local_rank = local_rank % max(1, torch.cuda.device_count())
   torch.cuda.set_device(local_rank)
   capi.check(capi.lib().soda_hip_set_device(local_rank))
-  dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+  if backend == 'nccl':
+    dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+  else:
+    dist.init_process_group(backend=backend)
   try:
     program, spec = open_program(args.app, args.iterate, args.jit)
     program.set_max_depth(args.max_depth)
@@ -357,7 +375,8 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
       return margin_table[k - 1]
 
     overlap = bool(getattr(args, 'overlap', False)) and world > 1
-    order = StreamSchedule(torch) if overlap else TimedSerialSchedule(torch)
+    order = (StreamSchedule if overlap else TimedSerialSchedule)(
+        torch, host_sync=backend != 'nccl')
 
     # Every exchange is inside the timed region, the level-0 one included: a step
     # starts from own rows only, as a fresh input would arrive.
@@ -378,7 +397,7 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
     dist.barrier()
     torch.cuda.synchronize()
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
-                           device=dev)
+                           device=dev if backend == 'nccl' else 'cpu')
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     wall = float(elapsed.item())
     exchange_ms = order.exchange_ms() / max(1, args.steps)

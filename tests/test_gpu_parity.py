@@ -767,6 +767,49 @@ def test_slab_decomposition_with_the_hip_engine(app, dims, world, exchange, iter
   assert np.array_equal(got[sl], want[sl])
 
 
+@pytest.mark.parametrize('app,dims,world,iterate,exchange,mode', [
+    ('jacobi2d', (1300, 900), 2, 70, 24, 'serial'),
+    ('jacobi2d', (1300, 1500), 3, 100, 20, 'overlap'),
+    ('jacobi3d', (130, 70, 200), 2, 20, 8, 'overlap')])
+def test_multi_process_slabs_on_one_gpu(tmp_path, app, dims, world, iterate, exchange,
+                                        mode):
+  """The multi-rank driver end to end with the real kernels: `world` processes (a
+  gloo group; all on this box's one GPU, so ghost rows go through the host instead
+  of RCCL) each run soda_hip.runtime.dist.run_slab with the HIP engine - serial
+  order, and the overlapping order (boundary bands first, exchange on a side
+  stream beside the interior sweep).  Own rows put together equal the oracle's
+  single-process result bit for bit."""
+  import socket
+  import subprocess
+  import sys
+  from conftest import ROOT
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+             WORLD_SIZE=str(world), OMP_NUM_THREADS='2')
+  procs = [subprocess.Popen(
+      [sys.executable, os.path.join(ROOT, 'tests', 'dist_gpu_worker.py'), app,
+       'x'.join(map(str, dims)), str(iterate), str(exchange), str(tmp_path), mode],
+      env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(world)]
+  for p in procs:
+    assert p.wait(timeout=600) == 0
+  spec = gpu_util.load_spec(app, iterate=iterate)
+  full = np.random.default_rng(99).random(tuple(reversed(dims)), dtype=np.float32)
+  orc = oracle(app)
+  want = orc.run([full], iterate=iterate)[spec['outputs'][0]]
+  got = np.zeros_like(want)
+  n_exchanges = []
+  for r in range(world):
+    start, stop, ex, n_ex, ms = open(os.path.join(tmp_path, 'rank%d.txt' % r)).read().split()
+    got[int(start):int(stop)] = np.load(os.path.join(tmp_path, 'rank%d.npy' % r))
+    n_exchanges.append(int(n_ex))
+  sl = orc.valid_slices(tuple(dims), iterate)
+  assert want[sl].size > 0 and np.array_equal(got[sl], want[sl])
+  assert min(n_exchanges) >= -(-iterate // exchange)
+
+
 def test_denormals_signed_zeros_and_infinities():
   """IEEE corner cases: subnormal inputs (no flush-to-zero on either side),
   negative zeros, infinities (inf - inf = NaN must appear in the same cells)."""

@@ -1,6 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out
-for n in 256 512; do
-TUNE_HIPCC=1 python3 tools/tune3d.py denoise3d $n 1 'rows=16,cols=1' 'rows=12,cols=1' 'rows=16,cols=1,waves_per_eu=3' 'rows=8,cols=2' 'rows=8,cols=1' 'fused=0' 2>&1 | grep -v amdgpu.ids
-done
+python3 -m pytest tests/test_gpu_parity.py -k "multi_process_slabs" -x -q 2>&1 | tail -15
+python3 bench.py --force-dist --steps 3 --warmup 1 --cpu-seconds 0 2>&1 | grep "^{" | cut -c1-2300
+SODA_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 2 --steps 2 --warmup 1 --cpu-seconds 0 --size 16384 4096 --iterate 200 2>&1 | grep "^{" | cut -c1-1500
+SODA_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29556 bench.py --gpus 2 --steps 2 --warmup 1 --cpu-seconds 0 --size 16384 4096 --iterate 200 --overlap 2>&1 | grep "^{" | cut -c1-900
