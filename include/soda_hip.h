@@ -163,8 +163,9 @@ typedef struct soda_hip_kernel {
   int32_t step_valu;  /* VALU issue cycles ONE workgroup (all its wavefronts
                          together) spends per streamed row / plane */
   int32_t step_bytes; /* HBM bytes one workgroup loads + stores per step */
-  int32_t xcd_tiles;  /* 1: the kernel takes a 1-D grid and places its tiles
-                         itself, XCD by XCD: the launcher cuts the plane of tiles
+  int32_t xcd_tiles;  /* N > 0: the kernel takes a 1-D grid and places its tiles
+                         itself, XCD by XCD (N = most tiles per super-tile; 1 =
+                         the plain round-robin deal): the launcher cuts the plane of tiles
                          (dimensions 0 and 1) into super-tiles of SX x SY tiles,
                          passes param[1] = SX | SY << 16 and param[2] = (super-
                          tiles along x) | (along y) << 16, and launches

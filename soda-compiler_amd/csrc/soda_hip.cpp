@@ -337,11 +337,12 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
     const int64_t limit = even <= slots ? slots : even + even * 3 / 100;
     int best_sx = 1, best_sy = 1;
     double best = -1;
-    // at most 3 tiles per super-tile: larger groups cut the PMC read bytes further
+    // (kernel_stream3d_wp asks for at most 3 tiles per super-tile, the block form
+    // for 1 = the plain deal.)  Larger groups cut the PMC read bytes further
     // (jacobi3d x200: reads 2.5x -> 1.7x the written bytes with groups up to 24)
     // but every one measured ran SLOWER (cfg5 6.2 -> 7.0-7.4 ms), also with the
     // XCDs evenly loaded; 1 x 3 / 3 x 1 are neutral to 7 % faster per launch
-    int max_group = 3;
+    int max_group = std::max(1, (int)desc.xcd_tiles);   // the kernel's own limit
     if (const char* env = tuning_env("SODA_HIP_XCD_GROUP")) max_group = std::max(1, atoi(env));
     for (int sx = 1; sx <= 8; ++sx)
       for (int sy = 1; sy <= 8; ++sy) {
@@ -564,6 +565,18 @@ int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
       bool empty;
       rc = make_launch(plan, seq[i], a, &l, &empty);
       if (rc) return rc;
+      // several kernels of this depth (3-D: the wave-pipelined form with 64 x 32
+      // tiles and the block form with 128 x 64 ones): the cheapest on THIS box -
+      // large boxes favour the big tiles, small ones the many small ones
+      if (!empty && l.est_us > 0)
+        for (int k : fused) {
+          if (k == seq[i] || plan->kernels[k].depth != desc.depth) continue;
+          Launch other;
+          bool other_empty;
+          if (make_launch(plan, k, a, &other, &other_empty) == 0 && !other_empty &&
+              other.est_us > 0 && other.est_us < l.est_us)
+            l = other;
+        }
       if (!empty) list->push_back(l);
       *max_depth_used = std::max(*max_depth_used, (int)desc.depth);
       done += desc.depth;

@@ -20,7 +20,7 @@ import tempfile
 
 from .. import __version__
 from . import (kernel_common, kernel_stage, kernel_stream2d, kernel_stream2d_wp,
-               kernel_stream3d, kernel_stream3d_wp)
+               kernel_stream3d, kernel_stream3d_blk, kernel_stream3d_wp)
 from . import spec as specmod
 
 DEFAULT_MAX_DEPTH = 12
@@ -62,6 +62,15 @@ WAVE_PIPELINE_MIN_DEPTH = 4
 ALIGN_FULL_MAX_DEPTH = 2
 # 3-D: depths beyond the single-wave form, built wave-pipelined (kernel_stream3d_wp)
 DEEP_3D_DEPTHS = (4,)
+# 3-D programs light on arithmetic get TWO depth-4 kernels: the wave-pipelined one
+# (64 x 32 tiles, three workgroups per CU) and the block form (128 x 64 tiles, one
+# 8-wavefront workgroup per CU, input planes prefetched one ahead); the run-time
+# prices both per launch.  jacobi3d per depth-4 launch, same call: 512^3 375 vs
+# 314 us, 256^3 49 vs 55, 128^3 27 vs 45; cfg5 (boxes 504^3 .. 112^3) 6.44 vs 6.04
+# ms with either alone.  heat3d (packed pair-rows in the wave-pipelined form):
+# 392 vs 378-398 us - not worth a second kernel.
+DEEP_3D_FORM = 'both'
+BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300)
 # ... for programs light enough on arithmetic: jacobi3d (weight 7) 417 us per
 # depth-4 launch against 2 x 374 us at depth 2, heat3d (15) 622 us against
 # 2 x 411 us; heavier programs are VALU-bound at depth 2 already
@@ -337,15 +346,18 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
     for depth in wanted3:
       # rows per lane: as many as the register file allows (taller tiles waste
       # less on the y halo)
-      options = {k: v for k, v in fused_options.items() if not k.startswith('wp_')}
+      options = {k: v for k, v in fused_options.items()
+                 if not k.startswith(('wp_', 'blk_')) and k != 'deep3d'}
       # (rows, columns) per lane: the tallest tile the register file allows (taller
       # tiles waste less on the y halo).  Programs with several live tensors
       # (denoise3d, lowered to g and output over the inputs f and u) fit with one
       # column per lane: 12 rows (156 VGPRs, three wavefronts per SIMD) before 16
       # (235 VGPRs, two) - denoise3d per sweep at 256^3 / 512^3: 160 / 971 us against
       # 200 / 999 us, the two per-stage launches 165 / 1281 us
+      narrow = [] if cols or len(spec['inputs']) == len(spec['outputs']) else \
+          [(12, 1), (16, 1)]      # (iteration chains go deep in the forms below)
       shapes = [(options.pop('rows'), cols or 2)] if 'rows' in options else \
-          [(16, cols or 2), (12, cols or 2)] + ([] if cols else [(12, 1), (16, 1)])
+          [(16, cols or 2), (12, cols or 2)] + narrow
       error = None
       for rows, lane_cols in shapes:
         try:
@@ -366,6 +378,23 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
     if len(spec['inputs']) == len(spec['outputs']) == 1 and (
         depths is not None or arithmetic_weight(spec) <= DEEP_3D_MAX_WEIGHT):
       for depth in deep:
+        form = fused_options.get('deep3d', DEEP_3D_FORM)
+        if form in ('blk', 'both') and (form == 'blk' or
+                                        arithmetic_weight(spec) <= PACKED_3D_LIGHT_WEIGHT):
+          # block form: all levels in every wavefront, edge rows through LDS
+          # (kernel_stream3d_blk).  Named <app>_fused_k<d>b; with 'both' it ships
+          # NEXT TO the wave-pipelined kernel and the run-time picks per launch
+          options = dict(BLOCK_3D_OPTIONS)
+          options.update({k[4:]: v for k, v in fused_options.items()
+                          if k.startswith('blk_')})
+          try:
+            ftext, entry = kernel_stream3d_blk.emit(spec, depth, **options)
+            parts.append(ftext)
+            table.append(annotate_cost(entry, spec))
+            if form == 'blk':
+              continue
+          except kernel_stream2d.NotFusable as e:
+            notes.append('depth %d not in block form: %s' % (depth, e))
         options = {k[3:]: v for k, v in fused_options.items()
                    if k in ('wp_rows', 'wp_groups', 'wp_prefetch', 'wp_vgpr_budget', 'wp_split',
                            'wp_lds_budget', 'wp_waves_per_eu', 'wp_loader', 'wp_sched_fence',

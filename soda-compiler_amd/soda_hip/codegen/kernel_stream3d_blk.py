@@ -1,0 +1,393 @@
+"""Fused 3-D kernels, block form: ALL stage instances of `depth` iterations in
+every wavefront, the plane tile of a workgroup cut into horizontal bands, one per
+wavefront, and only the bands' EDGE ROWS exchanged through LDS.
+
+Why: the wave-pipelined form (kernel_stream3d_wp: one level per
+wavefront, whole plane tiles handed from wavefront to wavefront) is latency-bound -
+its wavefronts wait for each other at the per-plane barrier 59 % of the time, a
+level's whole tile makes an LDS round trip per plane, and 48 KiB + 168 VGPRs per
+workgroup cap the CU at three workgroups.  Here a wavefront is a vertical stack of
+levels for ITS rows (the single-wave form of kernel_stream3d, which fits two
+levels, cut to R = 8 rows so that four fit), and what a band needs from its
+neighbours is one or two rows per level and plane:
+
+  * lane l of wavefront w holds C columns x R rows of every live plane of every
+    level: columns wx + l*C.., rows wy + w*R..; x-neighbours by DPP wave shifts,
+    y-neighbours inside the band are registers;
+  * after producing a plane of level k a wavefront publishes its first and last
+    rows in LDS (double-buffered by step parity); rows above / below the band are
+    read from the neighbours' published rows ONE STEP LATER (one `s_barrier` per
+    streamed plane) - for a 7-point stencil that costs no extra latency, because a
+    level trails its parent by one plane anyway (it reads plane z+1);
+  * the workgroup's tile is (64*C) x (G*R) cells: 128 x 64 with C = 2, R = 8 and
+    G = 8 wavefronts keeps 120 x 56 = 82 % of itself at depth 4, where the 64 x 32
+    tile of the wave-pipelined form keeps 66 %;
+  * every wavefront runs the same code (no per-wavefront branches): a quarter of
+    the instruction footprint, equal work per wavefront by construction;
+  * tiles that would overhang the array are moved inside it and store only their
+    own cells; loads and stores are raw buffer instructions on a per-plane resource
+    (SGPR row offsets, one VGPR lane offset, out-of-range offsets for lanes that
+    must not store); placement is XCD-aware (see kernel_stream3d_wp, xcd_tiles).
+
+Reference correspondence: SODA's chain of compute modules (reference
+src/soda/dataflow.py:122-346) replicated across `unroll factor` PEs; the PEs are
+the wavefronts of a workgroup here, and what the FPGA's line buffers forward
+between neighbouring PEs are the published edge rows.
+
+Scope: one input, one output, 4-byte elements, x offsets within C columns,
+y offsets within R rows.
+"""
+from . import spec as specmod
+from .kernel_common import builtin_type, device_expr, tensor_index
+from .kernel_stream2d import LANES, Instance, NotFusable
+from .kernel_stream3d import kernel_name
+
+
+def build_chain(spec, depth, prefetch):
+  """Stage instances with lags along z.  A read with dy != 0 may need a
+  neighbouring wavefront's rows, which are visible one step after they were
+  produced."""
+  if len(spec['outputs']) != 1 or len(spec['inputs']) != 1:
+    raise NotFusable('one input, one output')
+  types = specmod.tensor_c_types(spec)
+  in_name = spec['inputs'][0]['name']
+  source = Instance('in_%s' % in_name, in_name, 0, types[in_name])
+  insts = [source]
+  current = {in_name: source}
+  for it in range(depth):
+    for stage in spec['stages']:
+      inst = Instance('k%d_%s' % (it, stage['name']), stage['name'], it,
+                      stage['c_type'], stage)
+      inst.reads = [(current[t], tuple(rel), t) for t, rel in stage['loads']]
+      insts.append(inst)
+      current[stage['name']] = inst
+    current[in_name] = current[spec['outputs'][0]]
+  final = current[spec['outputs'][0]]
+  final.final = True
+  source.lag = 0
+  source.ready = prefetch          # steps after its load at which a plane exists
+  for inst in insts[1:]:
+    inst.ready = 0
+    inst.lag = max(src.lag + src.ready + rel[2] + (1 if rel[1] else 0)
+                   for src, rel, _ in inst.reads)
+  for inst in insts:
+    inst.up = inst.down = 0        # rows the bands above / below need from this one
+    inst.age = 0                   # steps a published row must stay readable
+  for inst in insts[1:]:
+    for src, rel, _ in inst.reads:
+      src.keep = max(src.keep, inst.lag - rel[2] - src.lag + 1)
+      if rel[1] < 0:               # the band below reads our LAST rows
+        src.down = max(src.down, -rel[1])
+      if rel[1] > 0:               # the band above reads our FIRST rows
+        src.up = max(src.up, rel[1])
+      if rel[1]:
+        src.age = max(src.age, inst.lag - rel[2] - src.lag - src.ready)
+  for inst in insts[1:]:
+    if not inst.final and inst.keep == 0:
+      raise NotFusable('stage %s is never read' % inst.tensor)
+  return insts, final
+
+
+def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
+         max_period=12, vgpr_budget=250, waves_per_eu=0, xcd_tiles=1):
+  """Returns (text, kernel table entry)."""
+  if spec['dim'] != 3:
+    raise NotFusable('3-D programs only')
+  types = specmod.tensor_c_types(spec)
+  index = tensor_index(spec)
+  in_type = spec['inputs'][0]['c_type']
+  out_name = spec['outputs'][0]
+  elem = specmod.ELEM_SIZE[in_type]
+  if any(specmod.ELEM_SIZE[t] != elem for t in types.values()) or elem != 4:
+    raise NotFusable('the block form handles 4-byte elements')
+  C, R, G = cols, rows, stack
+  suffix = {4: 'b32', 8: 'b64', 16: 'b128'}.get(C * elem)
+  if suffix is None:
+    raise NotFusable('4-, 8- or 16-byte lanes')
+  buf_type = {4: 'unsigned', 8: 'soda_u2', 16: 'soda_u4'}[C * elem]
+  insts, final = build_chain(spec, depth, prefetch)
+  source = insts[0]
+  margins = specmod.iteration_margins(spec, depth)
+  lo, hi = margins[-1]
+  halo_lo = -(-lo[0] // C) * C
+  halo_hi = -(-hi[0] // C) * C
+  w_out = LANES * C - halo_lo - halo_hi
+  TR = G * R
+  y_lo, y_hi = lo[1], hi[1]
+  r_out = TR - y_lo - y_hi
+  if w_out < C or r_out < 1:
+    raise NotFusable('depth %d leaves no output cells in a %dx%d tile'
+                     % (depth, LANES * C, TR))
+  for inst in insts:
+    for src, rel, _ in inst.reads:
+      if abs(rel[0]) > C:
+        raise NotFusable('x offset %d exceeds the %d columns a lane holds'
+                         % (rel[0], C))
+      if abs(rel[1]) > R:
+        raise NotFusable('y offset %d exceeds the %d rows a band holds' % (rel[1], R))
+  slots = max([i.age for i in insts]) + 1
+  slots = max(2, slots)
+  best = None
+  for candidate in range(1, max_period + 1):
+    if max(inst.keep for inst in insts) > candidate or candidate % slots:
+      continue
+    divisors = [d for d in range(1, candidate + 1) if candidate % d == 0]
+    padded = [min(d for d in divisors if d >= inst.keep) if inst.keep else 0
+              for inst in insts]
+    cost = (sum(padded), candidate)
+    if best is None or cost < best[0]:
+      best = (cost, candidate, padded)
+  if best is None:
+    raise NotFusable('windows exceed the rotation period limit')
+  period = best[1]
+  for inst, keep in zip(insts, best[2]):
+    inst.keep = keep
+  est_vgprs = sum(inst.keep * R * C for inst in insts) + R * C + 32
+  if est_vgprs > vgpr_budget:
+    raise NotFusable('a wavefront would need about %d VGPRs (budget %d)'
+                     % (est_vgprs, vgpr_budget))
+  publishers = [i for i in insts if i.up or i.down]
+  edge_rows = max([i.up + i.down for i in publishers] or [1])
+  lds_bytes = len(publishers) * slots * (G + 2) * edge_rows * LANES * C * elem
+  if lds_bytes > 150 * 1024:
+    raise NotFusable('edge rows need %d bytes of LDS' % lds_bytes)
+  name = kernel_name(spec, depth) + 'b'    # next to the wave-pipelined kernel
+  L = final.lag
+  T = builtin_type(in_type)
+  vec = 'vec_%s' % name
+  o = []
+  line = o.append
+  line('// fused depth-%d 3-D kernel, block form: %d wavefronts x (%d x %d) bands ='
+       % (depth, G, LANES * C, R))
+  line('// tile %d x %d (%d x %d out), rotation period %d, prefetch %d, ~%d VGPRs, '
+       '%d KiB LDS (edge rows, %d slots)' % (LANES * C, TR, w_out, r_out, period,
+                                             prefetch, est_vgprs, lds_bytes // 1024,
+                                             slots))
+  for inst in insts:
+    line('//   %-18s lag %2d keep %2d  publishes %d first / %d last rows%s' % (
+        inst.ident, inst.lag, inst.keep, inst.up, inst.down,
+        '  -> HBM' if inst.final else ''))
+  line('typedef %s %s __attribute__((ext_vector_type(%d), aligned(%d)));'
+       % (T, vec, C, C * elem))
+  line('typedef unsigned soda_u2 __attribute__((ext_vector_type(2)));')
+  line('typedef unsigned soda_u4 __attribute__((ext_vector_type(4)));')
+
+  def slot(inst, u, back):
+    return (u - back) % inst.keep
+
+  pub_index = {id(inst): k for k, inst in enumerate(publishers)}
+
+  def edge(src, step, wave_expr, row):
+    """LDS row `row` (0 .. up-1: the band's first rows, up .. : its last rows) of
+    what `src` published at unrolled step `step`."""
+    return 'edges[%d][%d][%s][%d]' % (pub_index[id(src)], step % slots, wave_expr, row)
+
+  def publish(inst, u, s):
+    """First `up` and last `down` rows of the plane in window slot s."""
+    for k in range(inst.up):
+      line('        { %s v;%s *(%s*)&%s[lane * %d] = v; }' % (
+          vec, ''.join(' v[%d] = %s[%d][%d][%d];' % (c, inst.ident, s, k, c)
+                       for c in range(C)), vec, edge(inst, u, 'wave + 1', k), C))
+    for k in range(inst.down):
+      line('        { %s v;%s *(%s*)&%s[lane * %d] = v; }' % (
+          vec, ''.join(' v[%d] = %s[%d][%d][%d];' % (
+              c, inst.ident, s, R - inst.down + k, c) for c in range(C)), vec,
+          edge(inst, u, 'wave + 1', inst.up + k), C))
+
+  line('DEV void %s_band(const soda_hip_args& a, const i64 xs, const i64 yb, '
+       'const i64 wx, const i64 wy, const i64 z0, const i64 z1, const int wave, '
+       'const int lane, %s (*edges)[%d][%d][%d][%d]) {'
+       % (name, T, slots, G + 2, edge_rows, LANES * C))
+  line('  const i64 W = a.dims[0], H = a.dims[1], D = a.dims[2];')
+  line('  const i64 plane = W * H;')
+  line('  const i64 plane_bytes = plane * %d;' % elem)
+  line('  const i64 x = wx + lane * %d;' % C)
+  line('  const i64 y_band = wy + wave * %d;     // first row of this band' % R)
+  line('  const unsigned lane_byte = (unsigned)((y_band * W + x) * %d);' % elem)
+  line('  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];')
+  line('  const i64 st_hi = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];'
+       % (w_out, w_out))
+  line('  const i64 st_ylo = a.box_lo[1] > yb + %d ? a.box_lo[1] : yb + %d;'
+       % (y_lo, y_lo))
+  line('  const i64 st_yhi = a.box_hi[1] < yb + %d ? a.box_hi[1] : yb + %d;'
+       % (TR - y_hi, TR - y_hi))
+  line('  const bool st_full = x >= st_lo && x + %d <= st_hi;' % C)
+  for c in range(C):
+    line('  const bool st_col%d = x + %d >= st_lo && x + %d < st_hi;' % (c, c, c))
+  line('  const bool st_ragged = __builtin_amdgcn_ballot_w64(!st_full && (%s)) != 0;'
+       % ' || '.join('st_col%d' % c for c in range(C)))
+  line('  const %s* __restrict__ g_in = (const %s*)a.tensor[%d];'
+       % (T, T, index[spec['inputs'][0]['name']]))
+  line('  %s* __restrict__ g_out = (%s*)a.tensor[%d];' % (T, T, index[out_name]))
+  for inst in insts:
+    if inst.keep:
+      line('  %s %s[%d][%d][%d];' % (builtin_type(inst.c_type), inst.ident,
+                                     inst.keep, R, C))
+      for k in range(inst.keep):
+        for r in range(R):
+          line('  ' + ' '.join('%s[%d][%d][%d] = 0;' % (inst.ident, k, r, c)
+                               for c in range(C)))
+  line('  i64 head = z0 - %d;' % lo[2])
+  line('  const i64 steps = (z1 - z0) + %d;' % (L + lo[2]))
+  line('  for (i64 n = 0; n < steps; n += %d, head += %d) {' % (period, period))
+
+  def operand(reader, src, rel, u, r, c):
+    back = reader.lag - src.lag - rel[2]
+    assert 0 <= back < src.keep, (reader.ident, src.ident, rel, back, src.keep)
+    s = slot(src, u, back)
+    rr = r + rel[1]
+    if rr < 0:        # the band above: its last rows
+      row = 'xa_%s_%d_%d' % (src.ident, s, src.down + rr)
+    elif rr >= R:     # the band below: its first rows
+      row = 'xb_%s_%d_%d' % (src.ident, s, rr - R)
+    else:
+      row = '%s[%d][%d]' % (src.ident, s, rr)
+    j = c + rel[0]
+    if 0 <= j < C:
+      return '%s[%d]' % (row, j)
+    if j < 0:
+      return 'from_lane_below(%s[%d])' % (row, C + j)
+    return 'from_lane_above(%s[%d])' % (row, j - C)
+
+  for u in range(period):
+    line('    {  // unrolled step %d' % u)
+    for inst in insts:
+      if inst.stage is None:
+        s = slot(inst, u, 0)
+        line('      { i64 zz = head + %d; if (zz > D - 1) zz = D - 1;' % u)
+        line('        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
+             'rsrc((void*)(g_in + zz * plane), 0, (int)plane_bytes, 0x27000);')
+        for r in range(R):
+          line('        { const %s v = __builtin_bit_cast(%s, __builtin_amdgcn_raw_'
+               'buffer_load_%s(rs, lane_byte, (unsigned)(%d * W * %d), 0));%s }' % (
+                   vec, vec, suffix, r, elem, ''.join(
+                       ' %s[%d][%d][%d] = v[%d];' % (inst.ident, s, r, c, c)
+                       for c in range(C))))
+        line('      }')
+        if inst.up or inst.down:    # the plane that "exists" from this step on
+          publish(inst, u, slot(inst, u, inst.ready))
+        continue
+      stage = inst.stage
+      ctype = builtin_type(inst.c_type)
+      by_name = {(n, rel): src for src, rel, n in inst.reads}
+      line('      {')
+      # rows of the neighbouring bands this stage reads
+      wanted = {}
+      for src, rel, _ in inst.reads:
+        if not rel[1]:
+          continue
+        back = inst.lag - src.lag - rel[2]
+        key = (src.ident, slot(src, u, back))
+        age = inst.lag - rel[2] - src.lag - src.ready
+        wanted[key] = (src, age)
+      for (ident, s), (src, age) in sorted(wanted.items()):
+        for k in range(src.down):     # last rows of the band above
+          line('        const %s xa_v_%s_%d_%d = *(const %s*)&%s[lane * %d];' % (
+              vec, ident, s, k, vec, edge(src, u - age, 'wave', src.up + k), C))
+          line('        const %s xa_%s_%d_%d[%d] = {%s};' % (
+              builtin_type(src.c_type), ident, s, k, C, ', '.join(
+                  'xa_v_%s_%d_%d[%d]' % (ident, s, k, c) for c in range(C))))
+        for k in range(src.up):       # first rows of the band below
+          line('        const %s xb_v_%s_%d_%d = *(const %s*)&%s[lane * %d];' % (
+              vec, ident, s, k, vec, edge(src, u - age, 'wave + 2', k), C))
+          line('        const %s xb_%s_%d_%d[%d] = {%s};' % (
+              builtin_type(src.c_type), ident, s, k, C, ', '.join(
+                  'xb_v_%s_%d_%d[%d]' % (ident, s, k, c) for c in range(C))))
+      if inst.final:
+        line('        %s out_tile[%d][%d];' % (ctype, R, C))
+      for r in range(R):
+        for c in range(C):
+          def load(tensor, rel, u=u, r=r, c=c, inst=inst, by_name=by_name):
+            return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, r, c)
+          target = ('out_tile[%d][%d]' % (r, c)) if inst.final else \
+              '%s[%d][%d][%d]' % (inst.ident, slot(inst, u, 0), r, c)
+          if stage['lets']:
+            line('        {')
+            for let in stage['lets']:
+              line('          const %s %s = %s;' % (
+                  builtin_type(let['c_type']), let['name'],
+                  specmod.substitute_loads(device_expr(let['expr']), load)))
+            line('          %s = %s;' % (target, specmod.substitute_loads(
+                device_expr(stage['expr']), load)))
+            line('        }')
+          else:
+            line('        %s = %s;' % (target, specmod.substitute_loads(
+                device_expr(stage['expr']), load)))
+      if inst.up or inst.down:
+        publish(inst, u, slot(inst, u, 0))
+      if inst.final:
+        line('        const i64 z = head + %d;' % (u - L))
+        line('        if (z >= z0 && z < z1) {')
+        line('          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
+             'rsrc((void*)(g_out + z * plane), 0, (int)plane_bytes, 0x27000);')
+        for r in range(R):
+          # the row predicate is wave-uniform: a scalar branch
+          line('          if (y_band + %d >= st_ylo && y_band + %d < st_yhi) {' % (r, r))
+          line('            if (!st_ragged) { %s v;%s __builtin_amdgcn_raw_buffer_store_%s('
+               '__builtin_bit_cast(%s, v), rs, st_full ? lane_byte : 0xfffffff0u, '
+               '(unsigned)(%d * W * %d), 0); }' % (
+                   vec, ''.join(' v[%d] = out_tile[%d][%d];' % (c, r, c)
+                                for c in range(C)), suffix, buf_type, r, elem))
+          line('            else {%s }' % ''.join(
+              ' __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, '
+              'out_tile[%d][%d]), rs, st_col%d ? lane_byte + %d : 0xfffffff0u, '
+              '(unsigned)(%d * W * %d), 0);' % (r, c, c, c * elem, r, elem)
+              for c in range(C)))
+          line('          }')
+        line('        }')
+      line('      }')
+    line('    }')
+    line('    soda_block_barrier();')
+  line('  }')
+  line('}')
+  line('')
+  occupancy = ''
+  if waves_per_eu > 0:
+    occupancy = ' __attribute__((amdgpu_waves_per_eu(%d, %d)))' % (waves_per_eu,
+                                                                   waves_per_eu)
+  line('GLOBAL WG_SIZE(%d)%s void %s(soda_hip_args a) {' % (G * LANES, occupancy, name))
+  line('  __attribute__((shared)) %s edges[%d][%d][%d][%d][%d];' % (
+      T, max(1, len(publishers)), slots, G + 2, edge_rows, LANES * C))
+  line('  const int lane = lane_id();')
+  line('  const int wave = __builtin_amdgcn_readfirstlane('
+       '__builtin_amdgcn_workitem_id_x() >> 6);')
+  if xcd_tiles:   # see kernel_stream3d_wp: super-tiles dealt to the XCDs
+    line('  const unsigned L = __builtin_amdgcn_workgroup_id_x();')
+    line('  const unsigned SX = (unsigned)a.param[1] & 0xffffu, '
+         'SY = (unsigned)a.param[1] >> 16;')
+    line('  const unsigned nsx = (unsigned)a.param[2] & 0xffffu, '
+         'nsy = (unsigned)a.param[2] >> 16;')
+    line('  const unsigned S = SX * SY, i = L >> 3, g = (i / S) * 8u + (L & 7u), '
+         'within = i % S;')
+    line('  const unsigned block_x = (g % nsx) * SX + within % SX;')
+    line('  const unsigned block_y = ((g / nsx) % nsy) * SY + within / SX;')
+    line('  const unsigned block_z = g / (nsx * nsy);')
+  else:
+    line('  const unsigned block_x = __builtin_amdgcn_workgroup_id_x();')
+    line('  const unsigned block_y = __builtin_amdgcn_workgroup_id_y();')
+    line('  const unsigned block_z = __builtin_amdgcn_workgroup_id_z();')
+  line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % C)
+  line('  const i64 xs = x_origin + (i64)block_x * %d;' % w_out)
+  line('  if (xs >= a.box_hi[0]) return;')
+  line('  const i64 yb = a.box_lo[1] + (i64)block_y * %d - %d;' % (r_out, y_lo))
+  line('  const i64 chunk = a.param[0] > 0 ? a.param[0] : %d;' % chunk_planes)
+  line('  const i64 z0 = a.box_lo[2] + (i64)block_z * chunk;')
+  line('  if (yb + %d >= a.box_hi[1] || z0 >= a.box_hi[2]) return;' % y_lo)
+  line('  const i64 z1 = z0 + chunk < a.box_hi[2] ? z0 + chunk : a.box_hi[2];')
+  # a tile that would overhang the array is moved inside it: every load is
+  # unguarded and the tile still stores only its own cells
+  line('  i64 wx = xs - %d;' % halo_lo)
+  line('  if (wx + %d > a.dims[0]) wx = a.dims[0] - %d;' % (LANES * C, LANES * C))
+  line('  if (wx < 0) wx = 0;')
+  line('  i64 wy = yb;')
+  line('  if (wy + %d > a.dims[1]) wy = a.dims[1] - %d;' % (TR, TR))
+  line('  if (wy < 0) wy = 0;')
+  line('  %s_band(a, xs, yb, wx, wy, z0, z1, wave, lane, edges);' % name)
+  line('}')
+  entry = dict(name=name, kind='fused', depth=depth, stage=-1,
+               block=[G * LANES, 1, 1], tile=[w_out, r_out, chunk_planes, 1],
+               origin_align=C, fill_rows=L + lo[2], cols=C, rows=R, stack=G,
+               prefetch=prefetch, period=period, est_vgprs=est_vgprs, w_out=w_out,
+               r_out=r_out, lds_bytes=lds_bytes, xcd_tiles=int(bool(xcd_tiles)),
+               min_extent=[LANES * C, TR])
+  return '\n'.join(o) + '\n', entry

@@ -174,12 +174,22 @@ def test_default_depth_sets():
 
 
 def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
-  """Depth-4 3-D kernel: one level per wavefront, 64x32 tiles, declares the
-  smallest array it accepts; programs it does not cover keep depth <= 2."""
+  """Depth-4 3-D kernels: the wave-pipelined one (one level per wavefront, 64x32
+  tiles) and, for programs light on arithmetic, the block form next to it (all
+  levels in every wavefront, 8 bands of 128x8 = 128x64 tiles, edge rows through
+  LDS); both declare the smallest array they accept; programs they do not cover
+  keep depth <= 2."""
   spec = spec_of('jacobi3d', iterate=8)
   text, table = kernel.generate(spec)
-  k4 = [k for k in table if k['kind'] == 'fused' and k['depth'] == 4]
+  blk = [k for k in table if k['kind'] == 'fused' and k['depth'] == 4 and k.get('stack')]
+  assert [k['name'] for k in blk] == ['jacobi3d_fused_k4b']
+  assert blk[0]['block'] == [512, 1, 1] and blk[0]['tile'][:2] == [120, 56]
+  assert blk[0]['min_extent'] == [128, 64] and blk[0]['prefetch'] == 1
+  assert blk[0]['xcd_tiles'] == 1 and blk[0]['fill_rows'] == 9
+  assert 'edges[' in text and 'soda_block_barrier' in text
+  k4 = [k for k in table if k['kind'] == 'fused' and k['depth'] == 4 and k.get('groups')]
   assert k4 and k4[0]['groups'] == 4 and k4[0]['block'] == [256, 1, 1]
+  assert k4[0]['xcd_tiles'] == 3 and k4[0]['buffer_io'] == 1
   assert k4[0]['min_extent'] == [64, 32] and k4[0]['tile'][:2] == [56, 24]
   assert k4[0]['lds_bytes'] <= 64 * 1024
   assert 'v_permlane32_swap' in text or 'rows_across_halves' in text
@@ -187,10 +197,10 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   # seams as scalar pairs
   assert k4[0]['pairs'] == 0
   packed_text, packed = kernel.generate(spec, wp_pairs=1)
-  assert [k['pairs'] for k in packed if k['depth'] == 4] == [1]
+  assert [k['pairs'] for k in packed if k['depth'] == 4 and k.get('groups')] == [1]
   assert 'pk2_shifted{' in packed_text
   heat = kernel.generate(spec_of('heat3d', iterate=8))[1]
-  assert [k['pairs'] for k in heat if k['depth'] == 4] == [1]
+  assert [k.get('pairs') for k in heat if k['depth'] == 4] == [1]    # no block form
   out = tmp_path / 'j3d.hsaco'
   kernel.compile_to_code_object(text, str(out))
   assert open(out, 'rb').read(4) == b'\x7fELF'

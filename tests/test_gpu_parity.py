@@ -253,6 +253,37 @@ def test_3d_wave_pipelined_forms_on_heat3d(options):
     prog.blob.unload()
 
 
+@pytest.mark.parametrize('app,options', [
+    ('jacobi3d', dict(deep3d='blk')),                      # 8 bands, prefetch 1
+    ('jacobi3d', dict(deep3d='blk', blk_stack=4, blk_prefetch=0)),
+    ('jacobi3d', dict(deep3d='blk', blk_stack=8, blk_rows=4, blk_prefetch=2)),
+    ('heat3d', dict(deep3d='blk', blk_stack=4))])
+def test_3d_block_form(app, options):
+  """The block form of the depth-4 3-D kernel (kernel_stream3d_blk: all levels in
+  every wavefront, bands of rows per wavefront, edge rows through LDS, tiles
+  moved inside the array, raw-buffer loads and stores) ALONE - no wave-pipelined
+  kernel next to it - on ragged shapes at and above its smallest array."""
+  from soda_hip.codegen import kernel
+  for shape, iterate in (((30, 64, 128), 4), ((45, 131, 140), 9), ((150, 70, 257), 13)):
+    spec = gpu_util.load_spec(app, iterate=iterate)
+    text, table = kernel.generate(spec, depths=[2, 4], **options)
+    deep = [k for k in table if k['depth'] == 4]
+    assert [bool(k.get('stack')) for k in deep] == [True], [k['name'] for k in deep]
+    if shape[1] < deep[0]['min_extent'][1] or shape[2] < deep[0]['min_extent'][0]:
+      continue
+    prog = host.open_program(source=text, spec=spec)
+    inputs = gpu_util.random_inputs(spec, shape)
+    got, timing = prog.run_numpy(inputs, iterate=iterate, timed=True)
+    assert timing['max_depth'] == 4
+    orc = soda_oracle.Oracle(spec)
+    want = orc.run(inputs, iterate=iterate)[spec['outputs'][0]]
+    sl = orc.valid_slices(tuple(reversed(shape)), iterate)
+    assert want[sl].size > 0
+    assert np.array_equal(got[0][sl], want[sl], equal_nan=True), (options, shape)
+    prog.close()
+    prog.blob.unload()
+
+
 def test_small_arrays_skip_kernels_without_a_guarded_path():
   """Arrays smaller than one 64x32 tile are served by the shallower fused
   kernels (soda_hip_kernel.min_extent), with the same results."""
