@@ -67,8 +67,8 @@ DEEP_3D_DEPTHS = (4,)
 # 8-wavefront workgroup per CU, input planes prefetched one ahead); the run-time
 # prices both per launch.  jacobi3d per depth-4 launch, same call: 512^3 375 vs
 # 314 us, 256^3 49 vs 55, 128^3 27 vs 45; cfg5 (boxes 504^3 .. 112^3) 6.44 vs 6.04
-# ms with either alone.  heat3d (packed pair-rows in the wave-pipelined form):
-# 392 vs 378-398 us - not worth a second kernel.
+# ms with either alone, 5.87 ms with the per-launch choice.  heat3d (packed pair-rows
+# in the wave-pipelined form): 392 vs 378 us per 512^3 launch.
 DEEP_3D_FORM = 'both'
 BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300)
 # ... for programs light enough on arithmetic: jacobi3d (weight 7) 417 us per
@@ -379,8 +379,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
         depths is not None or arithmetic_weight(spec) <= DEEP_3D_MAX_WEIGHT):
       for depth in deep:
         form = fused_options.get('deep3d', DEEP_3D_FORM)
-        if form in ('blk', 'both') and (form == 'blk' or
-                                        arithmetic_weight(spec) <= PACKED_3D_LIGHT_WEIGHT):
+        if form in ('blk', 'both'):
           # block form: all levels in every wavefront, edge rows through LDS
           # (kernel_stream3d_blk).  Named <app>_fused_k<d>b; with 'both' it ships
           # NEXT TO the wave-pipelined kernel and the run-time picks per launch

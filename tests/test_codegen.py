@@ -200,7 +200,8 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   assert [k['pairs'] for k in packed if k['depth'] == 4 and k.get('groups')] == [1]
   assert 'pk2_shifted{' in packed_text
   heat = kernel.generate(spec_of('heat3d', iterate=8))[1]
-  assert [k.get('pairs') for k in heat if k['depth'] == 4] == [1]    # no block form
+  assert [k.get('pairs') for k in heat if k['depth'] == 4 and k.get('groups')] == [1]
+  assert [k['name'] for k in heat if k.get('stack')] == ['heat3d_fused_k4b']
   out = tmp_path / 'j3d.hsaco'
   kernel.compile_to_code_object(text, str(out))
   assert open(out, 'rb').read(4) == b'\x7fELF'
