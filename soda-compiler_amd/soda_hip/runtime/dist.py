@@ -147,8 +147,8 @@ def band_plan(plan, step):
   return bands, interior
 
 
-def run_slab(engine, plan, arrays, iterate, margins_of, dist, depth_multiple=1,
-             ghosts_ready=False, schedule=None):
+def run_slab(engine, plan, arrays, iterate, margins_of, dist, ghosts_ready=False,
+             schedule=None):
   """Advances the slab `iterate` iterations.  `arrays` = [A, B, C]: A holds the
   level-0 slab (own rows filled, ghost rows anything) and is not written; the
   result ends up in the returned array (B or C).  Returns (array, exchanges).
