@@ -662,6 +662,43 @@ def test_per_stage_kernels_beyond_the_grid_limit():
   assert np.array_equal(staged[1:-1, 1:-1, 1:-1], want[1:-1, 1:-1, 1:-1])
 
 
+def test_half_program_against_ieee_binary16_arithmetic():
+  """`half` programs have no reference answer here (the reference's golden loop
+  needs Xilinx's hls_half.h, g++ 11 has no _Float16 in C++): they are checked against
+  IEEE binary16 arithmetic emulated with numpy - every `half op half` rounded to
+  half (float32 holds the exact sum / product of two halves, so rounding it once
+  is the correctly rounded half result), `half * float-literal` promoted to float
+  as in C++ and rounded on the store - on the fused and the per-stage kernels, two
+  iterations.  Unpinned against the reference, pinned against IEEE."""
+  from soda_hip import frontend
+  from soda_hip.codegen import kernel, spec as specmod
+  text = ('kernel: halfj\nburst width: 512\nunroll factor: 2\niterate: 2\n'
+          'input half: a(32, *)\n'
+          'output half: b(0, 0) = (a(0, 1) + a(1, 0) + a(0, 0) + a(0, -1) + a(-1, 0))'
+          ' * 0.2f\n')
+  spec = specmod.spec_from_stencil(frontend.loads(text))
+  src, table = kernel.generate(spec)
+  prog = host.open_program(source=src, spec=spec)
+  a = np.random.default_rng(21).random((90, 333), dtype=np.float32).astype(np.float16)
+
+  def step(x):
+    s = x[2:, 1:-1] + x[1:-1, 2:]          # float16 + float16 -> rounded to float16
+    s = s + x[1:-1, 1:-1]
+    s = s + x[:-2, 1:-1]
+    s = s + x[1:-1, :-2]
+    out = np.zeros_like(x)
+    out[1:-1, 1:-1] = (s.astype(np.float32) * np.float32(0.2)).astype(np.float16)
+    return out
+  want = step(step(a))
+  for max_depth in (0, 1, -1):
+    prog.set_max_depth(max_depth)
+    got = prog.run_numpy([a], iterate=2)[0]
+    assert got.dtype == np.float16
+    assert np.array_equal(got[2:-2, 2:-2], want[2:-2, 2:-2]), max_depth
+  prog.close()
+  prog.blob.unload()
+
+
 def test_one_dimensional_program_jit():
   """A 1-D program (the grammar's `name(*)` form): per-stage kernels, JIT path,
   iterate 3, against the oracle."""
