@@ -185,7 +185,12 @@ typedef struct soda_hip_args {
 
 /* ---- plan -------------------------------------------------------------------
  * A program bound to a blob.  Owns its scratch device memory (ping-pong partner
- * of the outputs, stage intermediates), sized on first use, freed on destroy. */
+ * of the outputs, stage intermediates), sized on first use, freed on destroy.
+ * Threading (reference: one host thread, one in-order queue, host.py:513): every
+ * entry point is synchronous on the host; a plan is NOT re-entrant - its scratch
+ * arrays and window tables are shared by its sweeps, so use one plan per host
+ * thread and per stream (plans are cheap; modules can be shared).  The error text
+ * of soda_hip_last_error() is per thread. */
 typedef struct soda_hip_plan soda_hip_plan;
 
 int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* program,
