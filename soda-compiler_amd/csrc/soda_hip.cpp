@@ -251,8 +251,10 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
                   desc.name, (long long)args.box_lo[d], (long long)args.box_hi[d], d,
                   (long long)args.dims[d]);
   for (int d = 0; d < 3; ++d) out->grid[d] = 1;
-  if (dim > 3) return fail(SODA_HIP_ERR_INTERNAL, "4-D launches are not implemented");
-  bool fold_rows = false;
+  if (dim > 3 && desc.kind != SODA_HIP_KERNEL_STAGE)
+    return fail(SODA_HIP_ERR_INTERNAL, "kernel %s: only per-stage kernels take 4-D boxes",
+                desc.name);
+  bool fold_rows = dim > 3;   // a 4-D box always goes as folded rows
   for (int d = 0; d < dim; ++d) {
     int64_t extent = args.box_hi[d] - args.box_lo[d];
     if (extent <= 0) { *empty = true; return 0; }
@@ -290,11 +292,12 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
                                          step_seconds(plan, k, blocks) * 1e6;
     }
     int64_t g = (extent + tile - 1) / tile;
-    if (d > 0 && desc.kind == SODA_HIP_KERNEL_STAGE && g > 65535) {
+    if (d > 0 && desc.kind == SODA_HIP_KERNEL_STAGE && (g > 65535 || dim > 3)) {
       // Per-stage kernels take one row (plane) per workgroup; past the 65535
-      // limit of grid.y / grid.z the rows and planes are folded into one index
-      // spread over grid.y x grid.z (kernel_stage.py; param[0] = 1 tells a 3-D
-      // kernel so).  Done after the loop, once every extent is known.
+      // limit of grid.y / grid.z - and for every 4-D box - the rows and planes are
+      // folded into one index spread over grid.y x grid.z (kernel_stage.py;
+      // param[0] = 1 tells a 3-D kernel so).  Done after the loop, once every
+      // extent is known.
       fold_rows = true;
       g = 1;
     }
@@ -302,12 +305,12 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
       return fail(SODA_HIP_ERR_EXTENTS_TOO_LARGE,
                   "grid dimension %d of kernel %s would be %lld", d, desc.name,
                   (long long)g);
-    out->grid[d] = (unsigned)g;
+    if (d < 3) out->grid[d] = (unsigned)g;
   }
   if (fold_rows) {
     int64_t rows = 1;
     for (int d = 1; d < dim; ++d) rows *= args.box_hi[d] - args.box_lo[d];
-    const int64_t gy = 65535, gz = (rows + gy - 1) / gy;
+    const int64_t gy = std::min<int64_t>(rows, 65535), gz = (rows + gy - 1) / gy;
     if (gz > 65535)
       return fail(SODA_HIP_ERR_EXTENTS_TOO_LARGE, "kernel %s: %lld rows", desc.name,
                   (long long)rows);
@@ -861,8 +864,9 @@ int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* progra
   if (!module || !program || !kernels || !plan)
     return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
   const soda_hip_program& p = *program;
-  if (p.dim < 1 || p.dim > 3)
-    return fail(SODA_HIP_ERR_CONSTRAINT, "dim %d not supported (1..3)", p.dim);
+  if (p.dim < 1 || p.dim > SODA_HIP_MAX_DIMS)
+    return fail(SODA_HIP_ERR_CONSTRAINT, "dim %d not supported (1..%d)", p.dim,
+                SODA_HIP_MAX_DIMS);
   if (p.n_inputs < 1 || p.n_stages < 1 || p.n_outputs < 1 ||
       p.n_inputs + p.n_stages > SODA_HIP_MAX_TENSORS || p.n_outputs > SODA_HIP_MAX_IO ||
       p.n_inputs > SODA_HIP_MAX_IO || p.n_windows < 1 || p.n_windows > SODA_HIP_MAX_WINDOWS)
@@ -1336,7 +1340,7 @@ int soda_hip_run_buffers(soda_hip_plan* plan, soda_hip_buffer_t* const* inputs,
   // only the valid interior goes back to the caller (host.py:838-899)
   for (int j = 0; j < p.n_outputs && !rc; ++j) {
     const int es = p.elem_size[p.output_tensor[j]];
-    int64_t lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1}, ext[3] = {1, 1, 1};
+    int64_t lo[4] = {0, 0, 0, 0}, hi[4] = {1, 1, 1, 1}, ext[4] = {1, 1, 1, 1};
     bool empty = false;
     // each output has its own composed window (host.py:1082-1091)
     const Box& ob = plan->boxes[iterate - 1][p.output_tensor[j]];
@@ -1345,17 +1349,23 @@ int soda_hip_run_buffers(soda_hip_plan* plan, soda_hip_buffer_t* const* inputs,
       if (hi[d] <= lo[d]) empty = true;
     }
     if (empty) continue;
-    hipMemcpy3DParms parms;
-    memset(&parms, 0, sizeof parms);
-    parms.srcPtr = make_hipPitchedPtr(dout[j], ext[0] * es, ext[0] * es, ext[1]);
-    parms.dstPtr = make_hipPitchedPtr(outputs[j]->host, ext[0] * es, ext[0] * es, ext[1]);
-    parms.srcPos = make_hipPos(lo[0] * es, lo[1], lo[2]);
-    parms.dstPos = make_hipPos(lo[0] * es, lo[1], lo[2]);
-    parms.extent = make_hipExtent((hi[0] - lo[0]) * es, hi[1] - lo[1], hi[2] - lo[2]);
-    parms.kind = hipMemcpyDeviceToHost;
-    if (hipMemcpy3D(&parms) != hipSuccess)
-      rc = fail(SODA_HIP_ERR_COPY_TO_HOST, "D2H copy of output %d failed: %s", j,
-                hipGetErrorString(hipGetLastError()));
+    // one 3-D copy per index of the fourth dimension
+    for (int64_t w = lo[3]; w < hi[3] && !rc; ++w) {
+      const size_t skip = (size_t)w * ext[0] * ext[1] * ext[2] * es;
+      hipMemcpy3DParms parms;
+      memset(&parms, 0, sizeof parms);
+      parms.srcPtr = make_hipPitchedPtr((char*)dout[j] + skip, ext[0] * es, ext[0] * es,
+                                        ext[1]);
+      parms.dstPtr = make_hipPitchedPtr((char*)outputs[j]->host + skip, ext[0] * es,
+                                        ext[0] * es, ext[1]);
+      parms.srcPos = make_hipPos(lo[0] * es, lo[1], lo[2]);
+      parms.dstPos = make_hipPos(lo[0] * es, lo[1], lo[2]);
+      parms.extent = make_hipExtent((hi[0] - lo[0]) * es, hi[1] - lo[1], hi[2] - lo[2]);
+      parms.kind = hipMemcpyDeviceToHost;
+      if (hipMemcpy3D(&parms) != hipSuccess)
+        rc = fail(SODA_HIP_ERR_COPY_TO_HOST, "D2H copy of output %d failed: %s", j,
+                  hipGetErrorString(hipGetLastError()));
+    }
   }
   cleanup();
   return rc;

@@ -249,6 +249,10 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
   w('          for (int64_t q = 0; q < inner_rows; ++q) {\n')
   if dim == 3:
     w('            if (q < mlo[1] || q >= in->extent[1] - mhi[1]) continue;\n')
+  if dim == 4:
+    w('            const int64_t q1 = q % in->extent[1], q2 = q / in->extent[1];\n')
+    w('            if (q1 < mlo[1] || q1 >= in->extent[1] - mhi[1] || q2 < mlo[2] || '
+      'q2 >= in->extent[2] - mhi[2]) continue;\n')
   w('            const size_t off = (size_t)(q * in->extent[0] + x0) * es;\n')
   w('            memcpy(out->host + y * row_bytes + off, stage.data() + '
     '(y - slab.own_first) * row_bytes + off, (size_t)(x1 - x0) * es);\n')

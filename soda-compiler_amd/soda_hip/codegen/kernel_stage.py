@@ -1,7 +1,7 @@
 """Per-stage kernels: one launch computes ONE stage of ONE iteration over its
 box, operands straight from global memory, intermediates through HBM.
 
-This is the general-purpose form (any dimension 1..3, any number of inputs and
+This is the general-purpose form (any dimension 1..4, any number of inputs and
 outputs, any window): the direct GPU counterpart of one loop nest of the
 reference's CPU golden model (reference host.py:1076-1117).  It is used (a) for
 programs the fused generators do not cover and (b) as the in-GPU cross-check of
@@ -68,7 +68,7 @@ def emit(spec):
       lines.append('  const i64 y = a.box_lo[1] + __builtin_amdgcn_workgroup_id_y() + '
                    '(i64)__builtin_amdgcn_workgroup_id_z() * __builtin_amdgcn_grid_size_y();')
       lines.append('  if (y >= a.box_hi[1]) return;')
-    if dim >= 3:
+    if dim == 3:
       lines.append('  i64 y = a.box_lo[1] + __builtin_amdgcn_workgroup_id_y();')
       lines.append('  i64 z = a.box_lo[2] + __builtin_amdgcn_workgroup_id_z();')
       lines.append('  if (a.param[0] == 1) {')
@@ -79,11 +79,24 @@ def emit(spec):
       lines.append('    z = a.box_lo[2] + n / ey;')
       lines.append('    if (z >= a.box_hi[2]) return;')
       lines.append('  }')
+    if dim == 4:
+      # four dimensions: the launcher always folds dimensions 1..3 into grid.y x grid.z
+      lines.append('  const i64 ey = a.box_hi[1] - a.box_lo[1];')
+      lines.append('  const i64 ez = a.box_hi[2] - a.box_lo[2];')
+      lines.append('  const i64 n = __builtin_amdgcn_workgroup_id_y() + '
+                   '(i64)__builtin_amdgcn_workgroup_id_z() * __builtin_amdgcn_grid_size_y();')
+      lines.append('  const i64 y = a.box_lo[1] + n % ey;')
+      lines.append('  const i64 z = a.box_lo[2] + n / ey % ez;')
+      lines.append('  const i64 w = a.box_lo[3] + n / (ey * ez);')
+      lines.append('  if (w >= a.box_hi[3]) return;')
     if dim >= 2:
       lines.append('  const i64 s1 = a.dims[0];')
     if dim >= 3:
       lines.append('  const i64 s2 = a.dims[0] * a.dims[1];')
-    cell = 'x' + (' + y * s1' if dim >= 2 else '') + (' + z * s2' if dim >= 3 else '')
+    if dim >= 4:
+      lines.append('  const i64 s3 = a.dims[0] * a.dims[1] * a.dims[2];')
+    cell = ('x' + (' + y * s1' if dim >= 2 else '') + (' + z * s2' if dim >= 3 else '')
+            + (' + w * s3' if dim >= 4 else ''))
     lines.append('  const i64 c = %s;' % cell)
     lines.append('  const bool whole = x + %d <= a.box_hi[0];' % V)
     seen = []
@@ -109,6 +122,8 @@ def emit(spec):
         base.append('(%d) * s1' % outer[0])
       if dim >= 3 and outer[1]:
         base.append('(%d) * s2' % outer[1])
+      if dim >= 4 and outer[2]:
+        base.append('(%d) * s3' % outer[2])
       width = hi - lo + V
       lines.append('  %s %s[%d];  // %s, outer offset %s, dx %d..%d'
                    % (tt, rid, width, tensor, list(outer), lo, hi))

@@ -435,7 +435,8 @@ def main_extra():
       ana, text = analysis_of(st)
       key = '%s.iter%d' % (app, st.iterate)
       analysis[key] = ana
-      for dims in [(37, 29), (64, 48)]:
+      for dims in {2: [(37, 29), (64, 48)], 3: CASES_3D,
+                   4: [(12, 10, 9, 8), (9, 11, 7, 10)]}[st.dim]:
         for kind in ('ramp', 'random'):
           inputs = make_inputs(st, dims, kind, np.random.default_rng(SEED))
           try:

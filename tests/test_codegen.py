@@ -249,6 +249,22 @@ def test_unfusable_programs_fall_back_to_stage_kernels():
   assert [k['depth'] for k in table if k['kind'] == 'fused'] == [1]
 
 
+def test_four_dimensional_programs_get_stage_kernels(tmp_path):
+  """Four dimensions is what `buffer_t` and `<app>_test(blob, dims[4])` allow
+  (reference header.py:36-48, host.py:992): per-stage kernels only, with the
+  fourth index and its stride in the cell address."""
+  import os
+  from conftest import SAMPLES
+  spec = specmod.spec_from_stencil(
+      frontend.load(os.path.join(SAMPLES, 'extra', 'hyper4d.soda')))
+  assert spec['dim'] == 4
+  text, table = kernel.generate(spec)
+  assert [k['kind'] for k in table] == ['stage']
+  assert 'w * s3' in text and '(-1) * s3' in text and '(1) * s3' in text
+  kernel.compile_to_code_object(text, str(tmp_path / 'hyper4d.hsaco'),
+                                extra_flags=['-Werror=array-bounds'])
+
+
 def test_pointwise_locals_are_folded_into_their_readers():
   """denoise: diff_*, r0, r1 are read only at offset 0 -> two stages remain; the
   cast reproduces the rounding of the removed store; windows are unchanged."""

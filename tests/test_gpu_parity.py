@@ -726,6 +726,41 @@ def test_one_dimensional_program_jit():
   prog.close()
 
 
+def test_four_dimensional_program(tmp_path, capfd):
+  """A 4-D program (`buffer_t` and `<app>_test(blob, dims[4])` stop at four
+  dimensions, reference header.py:36-48, host.py:992): per-stage kernels with
+  dimensions 1..3 folded into grid.y x grid.z.  Small boxes are pinned to the
+  reference's own CPU loops by the extra.hyper4d fixtures (test_fixture); here a
+  larger box against the oracle, the Python `<app>_test` and the generated C++
+  host program."""
+  import subprocess
+  import sys
+  from conftest import ROOT
+  spec = gpu_util.load_spec('hyper4d')
+  assert spec['dim'] == 4
+  inputs = gpu_util.random_inputs(spec, (11, 23, 31, 203))
+  check('hyper4d', inputs, 1)
+  check('hyper4d', inputs, 4)
+  blob = os.path.join(gpu_util.BLOBS, 'hyper4d.hsaco')
+  assert host.app_test(spec, blob, [37, 12, 11, 10]) == 0
+  out, err = capfd.readouterr()
+  assert 'INFO: PASS!' in err
+  sodac = os.path.join(ROOT, 'soda-compiler_amd', 'sodac')
+  csrc = os.path.join(ROOT, 'soda-compiler_amd', 'csrc')
+  src = tmp_path / 'hyper4d_host.cpp'
+  subprocess.check_call([sys.executable, sodac, gpu_util.sample_path('hyper4d'),
+                         '--hip-host-cpp', str(src)])
+  exe = tmp_path / 'hyper4d_host'
+  subprocess.check_call(['g++', '-std=c++11', '-O1', '-fopenmp', '-ffp-contract=off',
+                         '-DSODA_HIP_MAIN', '-I', os.path.join(ROOT, 'include'),
+                         str(src), '-L', csrc, '-lsoda_hip', '-Wl,-rpath,' + csrc,
+                         '-o', str(exe)])
+  r = subprocess.run([str(exe), blob, '37', '12', '11', '10'], capture_output=True,
+                     text=True, env=dict(os.environ, SODA_ITERATE='3'))
+  assert r.returncode == 0, r.stderr
+  assert 'INFO: PASS!' in r.stderr
+
+
 def test_multi_output_program_uses_stage_kernels():
   """Two outputs with different windows: each output is defined on its own box
   (reference host.py:1082-1091); only the per-stage kernels can honour that."""
@@ -782,7 +817,7 @@ def test_multi_output_host_buffer_protocol():
     ('jacobi2d', (1500, 611), 2, 12, 30), ('jacobi2d', (1500, 611), 3, 5, 17),
     ('jacobi2d', (1500, 611), 4, 24, 48), ('jacobi2d', (900, 1400), 2, 144, 300),
     ('jacobi3d', (130, 70, 96), 2, 8, 20), ('jacobi3d', (67, 45, 120), 3, 4, 13),
-    ('heat3d', (100, 64, 90), 2, 12, 24)])
+    ('heat3d', (100, 64, 90), 2, 12, 24), ('hyper4d', (40, 14, 13, 33), 3, 2, 5)])
 def test_slab_decomposition_with_the_hip_engine(app, dims, world, exchange, iterate):
   """The multi-GPU driver's slab logic (soda_hip.runtime.dist) run with the REAL
   kernels: all ranks emulated on this one GPU, ghost rows copied by hand where
