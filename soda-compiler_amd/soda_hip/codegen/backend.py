@@ -44,8 +44,11 @@ def add_arguments(parser):
                       metavar='file', help='gfx950 code object (runs hipcc)')
   parser.add_argument('--hip-max-depth', type=int, dest='hip_max_depth',
                       metavar='K', help='deepest fused (time-tiled) kernel to '
-                      'emit; iterations per launch (default %d)'
-                      % kernel.DEFAULT_MAX_DEPTH)
+                      'emit, in iterations per launch, never deeper than the '
+                      'program iterates (default %d; with the default, programs '
+                      'the packed wave-pipelined form covers also get depths %s)'
+                      % (kernel.DEFAULT_MAX_DEPTH,
+                         ', '.join(map(str, kernel.PACKED_DEEP_DEPTHS))))
   parser.add_argument('--hip-cols', type=int, dest='hip_cols', metavar='C',
                       help='columns per lane (default: 16-byte vectors, capped '
                       'by burst width)')

@@ -90,13 +90,21 @@ def test_analysis_matches_reference(key):
       if one_sided and field in ('loop_lo', 'loop_hi_margin'):
         assert min(mine[field]) >= 0
         continue
+      if field == 'is_output' and mine['name'] in st.output_names:
+        # the reference calls a tensor an output when nothing reads it
+        # (core.py:146); a declared output that feeds another stage is still an
+        # output here (it is handed back to the caller all the same)
+        assert mine[field]
+        continue
       assert mine[field] == theirs[field], (field, mine['name'])
     # the reference sorts each parent's loads by linearised offset
     # (core.py:389-395); compare as multisets per parent
     assert {k: sorted(v) for k, v in mine['loads'].items()} == \
         {k: sorted(v) for k, v in theirs['loads'].items()}
   # STENCIL_DIM_n macros of the generated host (host.py:1183-1186)
-  lo, hi = ours[-1]['loop_lo'], ours[-1]['loop_hi_margin']
+  # ... which the reference takes from the FIRST output's window (host.py:1183-1186)
+  first = [t for t in ours if t['name'] == st.output_names[0]][-1]
+  lo, hi = first['loop_lo'], first['loop_hi_margin']
   for d in range(st.dim):
     assert one_sided or ref['macros']['STENCIL_DIM_%d' % d] == lo[d] + hi[d] + 1
 

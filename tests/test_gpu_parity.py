@@ -813,6 +813,36 @@ def test_multi_output_host_buffer_protocol():
   prog.close()
 
 
+def test_output_that_feeds_another_output():
+  """tests/samples/extra/outchain.soda: `second` reads `first`, both are outputs.
+  The reference's own CPU loops have no self-contained answer for such a program
+  (they keep `first` in a scalar, read the DEVICE's `first` array for `second` and
+  never compare `first`: host.py:1104-1118, core.py:146; extra_manifest.json records
+  it), so the device result is checked against the oracle and against numpy: each
+  output on its own box, the host-buffer entry leaving the rest untouched."""
+  prog = program('outchain')
+  assert all(k['kind'] == 'stage' for k in prog.kernels)
+  a = np.random.default_rng(5).random((90, 150), dtype=np.float32)
+  f32 = np.float32
+  m = (a[:-1, :-1] + a[:-1, 1:] + a[1:, :-1]) * f32(0.25)     # rows 0..H-2, cols 0..W-2
+  first = m[:, 1:] - m[:, :-1] * f32(0.5)                      # rows 0..H-2, cols 1..W-2
+  second = (first[:-2, :-1] + first[2:, 1:]) + a[1:-2, 1:-2] * f32(2.0)
+  got1, got2 = prog.run_numpy([a], iterate=1)
+  assert np.array_equal(got1[:-1, 1:-1], first)
+  assert np.array_equal(got2[1:-2, 1:-2], second)
+  want = oracle('outchain').run([a], iterate=1)
+  assert np.array_equal(want['first'][:-1, 1:-1], first)
+  assert np.array_equal(want['second'][1:-2, 1:-2], second)
+  o1 = np.full_like(a, -1.0)
+  o2 = np.full_like(a, -1.0)
+  prog.run_buffers([a], [o1, o2], 1)
+  assert np.array_equal(o1[:-1, 1:-1], first) and np.array_equal(o2[1:-2, 1:-2], second)
+  for o, inner in ((o1, (slice(0, -1), slice(1, -1))), (o2, (slice(1, -2), slice(1, -2)))):
+    rest = np.ones(a.shape, bool)
+    rest[inner] = False
+    assert (o[rest] == -1).all()
+
+
 @pytest.mark.parametrize('app,dims,world,exchange,iterate', [
     ('jacobi2d', (1500, 611), 2, 12, 30), ('jacobi2d', (1500, 611), 3, 5, 17),
     ('jacobi2d', (1500, 611), 4, 24, 48), ('jacobi2d', (900, 1400), 2, 144, 300),
