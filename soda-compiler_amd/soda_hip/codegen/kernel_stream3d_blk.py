@@ -40,6 +40,7 @@ y offsets within R rows.
 from . import spec as specmod
 from .kernel_common import builtin_type, device_expr, tensor_index
 from .kernel_stream2d import LANES, Instance, NotFusable
+from .kernel_stream2d_wp import packable
 from .kernel_stream3d import kernel_name
 
 
@@ -89,8 +90,27 @@ def build_chain(spec, depth, prefetch):
 
 
 def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
-         max_period=12, vgpr_budget=250, waves_per_eu=0, xcd_tiles=1):
-  """Returns (text, kernel table entry)."""
+         max_period=12, vgpr_budget=250, waves_per_eu=0, xcd_tiles=1, ring=0,
+         pairs=0):
+  """Returns (text, kernel table entry).
+
+  `prefetch` = input planes loaded ahead into REGISTERS (R*C VGPRs each);
+  `ring` = N > 0: instead, every wavefront keeps N planes of its band in flight as
+  LDS-direct loads (`global_load_lds_dwordx4`, no registers) into its own N-slot
+  LDS ring: at step t it waits for exactly plane t (explicit vmcnt: loads and
+  stores retire in issue order on gfx9, so the wait counts both - which is why a
+  ring kernel issues the SAME number of stores every step, dropped by an
+  out-of-range offset where nothing is to be stored), reads it into the input
+  window's registers and refills the slot with plane t + N.
+  `pairs` = 1 (float programs of + - * /, kernel_stream2d_wp.packable): band rows p
+  and p + R/2 of a lane share a 64-bit register pair, so a level's plane is R/2
+  pair-rows of v_pk_add_f32 / v_pk_mul_f32.  The y-neighbour of a pair-row is the
+  next pair-row except at the seams (the low halves' row above the band and the
+  high halves' row below it come from the neighbouring bands' edge rows, rows
+  R/2-1 -> R/2 are a low half meeting its own high half): those operands, and the
+  lane-crossing x-neighbours, are two scalars each (kernel_common: pk2_shifted,
+  the DPP shift folded into a v_add_f32_dpp).  Same IEEE operations in the same
+  order as the scalar form."""
   if spec['dim'] != 3:
     raise NotFusable('3-D programs only')
   types = specmod.tensor_c_types(spec)
@@ -101,12 +121,22 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   if any(specmod.ELEM_SIZE[t] != elem for t in types.values()) or elem != 4:
     raise NotFusable('the block form handles 4-byte elements')
   C, R, G = cols, rows, stack
+  pairs = int(bool(pairs))
+  if pairs and (R % 2 or not packable(spec)):
+    raise NotFusable('packed pair-rows: an even number of rows and a plain float program')
+  RP = R // 2 if pairs else R      # register rows per lane (pair-rows when packed)
   suffix = {4: 'b32', 8: 'b64', 16: 'b128'}.get(C * elem)
   if suffix is None:
     raise NotFusable('4-, 8- or 16-byte lanes')
   buf_type = {4: 'unsigned', 8: 'soda_u2', 16: 'soda_u4'}[C * elem]
+  if ring and prefetch:
+    raise NotFusable('ring and register prefetch exclude each other')
   insts, final = build_chain(spec, depth, prefetch)
   source = insts[0]
+  rows_per_load = 16 // (C * elem)     # a 16-byte-per-lane load covers this many rows
+  if ring and (rows_per_load < 1 or R % rows_per_load):
+    raise NotFusable('ring: %d rows per load do not divide %d rows' % (rows_per_load, R))
+  ring_loads = R // max(1, rows_per_load)
   margins = specmod.iteration_margins(spec, depth)
   lo, hi = margins[-1]
   halo_lo = -(-lo[0] // C) * C
@@ -123,13 +153,14 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
       if abs(rel[0]) > C:
         raise NotFusable('x offset %d exceeds the %d columns a lane holds'
                          % (rel[0], C))
-      if abs(rel[1]) > R:
-        raise NotFusable('y offset %d exceeds the %d rows a band holds' % (rel[1], R))
+      if abs(rel[1]) > RP:
+        raise NotFusable('y offset %d exceeds the %d rows a band holds' % (rel[1], RP))
   slots = max([i.age for i in insts]) + 1
   slots = max(2, slots)
   best = None
   for candidate in range(1, max_period + 1):
-    if max(inst.keep for inst in insts) > candidate or candidate % slots:
+    if max(inst.keep for inst in insts) > candidate or candidate % slots or \
+        (ring and candidate % ring):
       continue
     divisors = [d for d in range(1, candidate + 1) if candidate % d == 0]
     padded = [min(d for d in divisors if d >= inst.keep) if inst.keep else 0
@@ -149,8 +180,9 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   publishers = [i for i in insts if i.up or i.down]
   edge_rows = max([i.up + i.down for i in publishers] or [1])
   lds_bytes = len(publishers) * slots * (G + 2) * edge_rows * LANES * C * elem
-  if lds_bytes > 150 * 1024:
-    raise NotFusable('edge rows need %d bytes of LDS' % lds_bytes)
+  ring_bytes = ring * G * R * LANES * C * elem
+  if lds_bytes + ring_bytes > 160 * 1024:
+    raise NotFusable('edge rows and ring need %d bytes of LDS' % (lds_bytes + ring_bytes))
   name = kernel_name(spec, depth) + 'b'    # next to the wave-pipelined kernel
   L = final.lag
   T = builtin_type(in_type)
@@ -170,10 +202,19 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('typedef %s %s __attribute__((ext_vector_type(%d), aligned(%d)));'
        % (T, vec, C, C * elem))
   line('typedef unsigned soda_u2 __attribute__((ext_vector_type(2)));')
+  # (by value: __builtin_bit_cast applied directly to the high element of a
+  # <2 x float> lvalue stored the LOW element in the ragged-edge path)
+  line('DEV unsigned %s_bits(%s v) { return __builtin_bit_cast(unsigned, v); }' % (name, T))
   line('typedef unsigned soda_u4 __attribute__((ext_vector_type(4)));')
 
   def slot(inst, u, back):
     return (u - back) % inst.keep
+
+  def cell(ident, s, r, c):
+    """Band row r, column c of window slot s as a scalar lvalue."""
+    if pairs:
+      return '%s[%d][%d][%d][%d]' % (ident, s, r % RP, c, r // RP)
+    return '%s[%d][%d][%d]' % (ident, s, r, c)
 
   pub_index = {id(inst): k for k, inst in enumerate(publishers)}
 
@@ -186,18 +227,40 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     """First `up` and last `down` rows of the plane in window slot s."""
     for k in range(inst.up):
       line('        { %s v;%s *(%s*)&%s[lane * %d] = v; }' % (
-          vec, ''.join(' v[%d] = %s[%d][%d][%d];' % (c, inst.ident, s, k, c)
+          vec, ''.join(' v[%d] = %s;' % (c, cell(inst.ident, s, k, c))
                        for c in range(C)), vec, edge(inst, u, 'wave + 1', k), C))
     for k in range(inst.down):
       line('        { %s v;%s *(%s*)&%s[lane * %d] = v; }' % (
-          vec, ''.join(' v[%d] = %s[%d][%d][%d];' % (
-              c, inst.ident, s, R - inst.down + k, c) for c in range(C)), vec,
+          vec, ''.join(' v[%d] = %s;' % (
+              c, cell(inst.ident, s, R - inst.down + k, c)) for c in range(C)), vec,
           edge(inst, u, 'wave + 1', inst.up + k), C))
 
+  def vmcnt(n):   # s_waitcnt vmcnt(N) only (expcnt and lgkmcnt left at their maxima)
+    return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14)
+
+  if ring:
+    # a band's plane from the wavefront's ring slot in one burst of reads the
+    # compiler does not see as LDS reads (in front of a visible read of memory
+    # that LDS-direct loads write it would wait for ALL of them;
+    # kernel_common: soda_lds_read_f4)
+    width = {4: 'b32', 8: 'b64', 16: 'b128'}[C * elem]
+    line('DEV void soda_ring_read_%s(const void* base, %s) {' % (
+        name, ', '.join('%s& v%d_%d' % (T, r, c) for r in range(R) for c in range(C))))
+    line('  %s;' % '; '.join('%s t%d' % (vec, r) for r in range(R)))
+    line('  asm volatile(%s' % ''.join(
+        '"ds_read_%s %%%d, %%%d offset:%d\\n\\t"\n               ' % (
+            width, r, R, r * LANES * C * elem) for r in range(R)))
+    line('               "s_waitcnt lgkmcnt(0)"')
+    line('               : %s' % ', '.join('"=&v"(t%d)' % r for r in range(R)))
+    line('               : "v"((unsigned)(unsigned long long)base) : "memory");')
+    for r in range(R):
+      line('  ' + ' '.join('v%d_%d = t%d[%d];' % (r, c, r, c) for c in range(C)))
+    line('}')
   line('DEV void %s_band(const soda_hip_args& a, const i64 xs, const i64 yb, '
        'const i64 wx, const i64 wy, const i64 z0, const i64 z1, const int wave, '
-       'const int lane, %s (*edges)[%d][%d][%d][%d]) {'
-       % (name, T, slots, G + 2, edge_rows, LANES * C))
+       'const int lane, %s (*edges)[%d][%d][%d][%d], %s (*in_ring)[%d][%d][%d]) {'
+       % (name, T, slots, G + 2, edge_rows, LANES * C, T, G if ring else 1,
+          R if ring else 1, LANES * C if ring else 1))
   line('  const i64 W = a.dims[0], H = a.dims[1], D = a.dims[2];')
   line('  const i64 plane = W * H;')
   line('  const i64 plane_bytes = plane * %d;' % elem)
@@ -221,17 +284,69 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('  %s* __restrict__ g_out = (%s*)a.tensor[%d];' % (T, T, index[out_name]))
   for inst in insts:
     if inst.keep:
-      line('  %s %s[%d][%d][%d];' % (builtin_type(inst.c_type), inst.ident,
-                                     inst.keep, R, C))
+      line('  %s %s[%d][%d][%d];' % ('pk2' if pairs else builtin_type(inst.c_type),
+                                     inst.ident, inst.keep, RP, C))
       for k in range(inst.keep):
-        for r in range(R):
-          line('  ' + ' '.join('%s[%d][%d][%d] = 0;' % (inst.ident, k, r, c)
+        for r in range(RP):
+          line('  ' + ' '.join('%s[%d][%d][%d] = %s;' % (
+              inst.ident, k, r, c, 'pk2{0.0f, 0.0f}' if pairs else '0')
                                for c in range(C)))
   line('  i64 head = z0 - %d;' % lo[2])
   line('  const i64 steps = (z1 - z0) + %d;' % (L + lo[2]))
+
+  def ring_load(slot_index, plane_expr, indent):
+    line(indent + '{ i64 zz = %s; if (zz > D - 1) zz = D - 1;' % plane_expr)
+    line(indent + '  const %s* p = g_in + zz * plane + dma_lane;' % T)
+    for i in range(ring_loads):
+      line(indent + '  __builtin_amdgcn_global_load_lds((const __attribute__(('
+           'address_space(1))) void*)(p + %d * W), (__attribute__((address_space(3)))'
+           ' void*)&in_ring[%d][wave][%d][0], 16, 0, 0);' % (
+               i * rows_per_load, slot_index, i * rows_per_load))
+    line(indent + '}')
+
+  if ring:
+    # lane l of an LDS-direct load moves 16 bytes: row l / per_row of the group of
+    # rows_per_load rows, 16-byte chunk l % per_row of it
+    per_row = LANES * C * elem // 16
+    line('  const i64 dma_lane = (y_band + lane / %d) * W + wx + (lane %% %d) * %d;'
+         % (per_row, per_row, 16 // elem))
+    for k in range(ring):
+      ring_load(k, 'head + %d' % k, '  ')
+    # the first planes are waited for outright; from step `ring` on the counted
+    # wait below is exact
+    line('  __builtin_amdgcn_s_waitcnt(%d);  // vmcnt(0)' % vmcnt(0))
   line('  for (i64 n = 0; n < steps; n += %d, head += %d) {' % (period, period))
 
+  def out_cell(r, c):
+    if pairs:
+      return 'out_tile[%d][%d][%d]' % (r % RP, c, r // RP)
+    return 'out_tile[%d][%d]' % (r, c)
+
+  def operand_pk(reader, src, rel, u, p, c):
+    """Packed form: the operand of pair-row p (band rows p and p + RP)."""
+    back = reader.lag - src.lag - rel[2]
+    assert 0 <= back < src.keep, (reader.ident, src.ident, rel, back, src.keep)
+    s = slot(src, u, back)
+    j = c + rel[0]
+    jj = j if 0 <= j < C else (C + j if j < 0 else j - C)
+    shift = None if 0 <= j < C else ('below' if j < 0 else 'above')
+    pp = p + rel[1]
+    if 0 <= pp < RP:
+      whole = '%s[%d][%d][%d]' % (src.ident, s, pp, jj)
+      return whole if shift is None else 'pk_from_lane_%s(%s)' % (shift, whole)
+    if pp < 0:     # low half: the band above's last rows; high half: low halves
+      lo = 'xa_%s_%d_%d[%d]' % (src.ident, s, src.down + pp, jj)
+      hi = '%s[%d][%d][%d][0]' % (src.ident, s, RP + pp, jj)
+    else:          # low half: the high halves; high half: the band below's first rows
+      lo = '%s[%d][%d][%d][1]' % (src.ident, s, pp - RP, jj)
+      hi = 'xb_%s_%d_%d[%d]' % (src.ident, s, pp - RP, jj)
+    if shift is not None:
+      lo, hi = ('from_lane_%s(%s)' % (shift, v) for v in (lo, hi))
+    return 'pk2_shifted{%s, %s}' % (lo, hi)
+
   def operand(reader, src, rel, u, r, c):
+    if pairs:
+      return operand_pk(reader, src, rel, u, r, c)
     back = reader.lag - src.lag - rel[2]
     assert 0 <= back < src.keep, (reader.ident, src.ident, rel, back, src.keep)
     s = slot(src, u, back)
@@ -252,6 +367,24 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   for u in range(period):
     line('    {  // unrolled step %d' % u)
     for inst in insts:
+      if inst.stage is None and ring:
+        s = slot(inst, u, 0)
+        # plane head+u was issued `ring` steps ago; since then this wavefront has
+        # issued ring-1 planes of loads and `ring` steps of (at least) R stores
+        wait = (ring - 1) * ring_loads + ring * R
+        line('      __builtin_amdgcn_s_waitcnt(%d);  // vmcnt(%d)' % (vmcnt(wait), wait))
+        line('      { %s t[%d][%d];' % (T, R, C))
+        line('        soda_ring_read_%s(&in_ring[%d][wave][0][lane * %d], %s);' % (
+            name, u % ring, C, ', '.join('t[%d][%d]' % (r, c)
+                                         for r in range(R) for c in range(C))))
+        for r in range(R):
+          line('        ' + ' '.join('%s = t[%d][%d];' % (cell(inst.ident, s, r, c), r, c)
+                                     for c in range(C)))
+        line('      }')
+        ring_load(u % ring, 'head + %d' % (u + ring), '      ')
+        if inst.up or inst.down:
+          publish(inst, u, s)
+        continue
       if inst.stage is None:
         s = slot(inst, u, 0)
         line('      { i64 zz = head + %d; if (zz > D - 1) zz = D - 1;' % u)
@@ -261,7 +394,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
           line('        { const %s v = __builtin_bit_cast(%s, __builtin_amdgcn_raw_'
                'buffer_load_%s(rs, lane_byte, (unsigned)(%d * W * %d), 0));%s }' % (
                    vec, vec, suffix, r, elem, ''.join(
-                       ' %s[%d][%d][%d] = v[%d];' % (inst.ident, s, r, c, c)
+                       ' %s = v[%d];' % (cell(inst.ident, s, r, c), c)
                        for c in range(C))))
         line('      }')
         if inst.up or inst.down:    # the plane that "exists" from this step on
@@ -293,9 +426,11 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
           line('        const %s xb_%s_%d_%d[%d] = {%s};' % (
               builtin_type(src.c_type), ident, s, k, C, ', '.join(
                   'xb_v_%s_%d_%d[%d]' % (ident, s, k, c) for c in range(C))))
+      if pairs:
+        ctype = 'pk2'
       if inst.final:
-        line('        %s out_tile[%d][%d];' % (ctype, R, C))
-      for r in range(R):
+        line('        %s out_tile[%d][%d];' % (ctype, RP, C))
+      for r in range(RP):
         for c in range(C):
           def load(tensor, rel, u=u, r=r, c=c, inst=inst, by_name=by_name):
             return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, r, c)
@@ -315,7 +450,31 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
                 device_expr(stage['expr']), load)))
       if inst.up or inst.down:
         publish(inst, u, slot(inst, u, 0))
-      if inst.final:
+      if inst.final and ring:
+        # the same number of stores every step (the counted wait above): a plane
+        # or row that is not to be stored gets out-of-range offsets
+        line('        const i64 z = head + %d;' % (u - L))
+        line('        const bool z_ok = z >= z0 && z < z1;')
+        line('        {')
+        line('          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
+             'rsrc((void*)(g_out + (z_ok ? z : z0) * plane), 0, (int)plane_bytes, '
+             '0x27000);')
+        for r in range(R):
+          line('          { const bool row_ok = z_ok && y_band + %d >= st_ylo && '
+               'y_band + %d < st_yhi;' % (r, r))
+          line('            if (!st_ragged) { %s v;%s __builtin_amdgcn_raw_buffer_store_%s('
+               '__builtin_bit_cast(%s, v), rs, row_ok && st_full ? lane_byte : '
+               '0xfffffff0u, (unsigned)(%d * W * %d), 0); }' % (
+                   vec, ''.join(' v[%d] = %s;' % (c, out_cell(r, c))
+                                for c in range(C)), suffix, buf_type, r, elem))
+          line('            else {%s }' % ''.join(
+              ' __builtin_amdgcn_raw_buffer_store_b32(%s_bits('
+              '%s), rs, row_ok && st_col%d ? lane_byte + %d : 0xfffffff0u, '
+              '(unsigned)(%d * W * %d), 0);' % (name, out_cell(r, c), c, c * elem, r, elem)
+              for c in range(C)))
+          line('          }')
+        line('        }')
+      elif inst.final:
         line('        const i64 z = head + %d;' % (u - L))
         line('        if (z >= z0 && z < z1) {')
         line('          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
@@ -326,18 +485,18 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
           line('            if (!st_ragged) { %s v;%s __builtin_amdgcn_raw_buffer_store_%s('
                '__builtin_bit_cast(%s, v), rs, st_full ? lane_byte : 0xfffffff0u, '
                '(unsigned)(%d * W * %d), 0); }' % (
-                   vec, ''.join(' v[%d] = out_tile[%d][%d];' % (c, r, c)
+                   vec, ''.join(' v[%d] = %s;' % (c, out_cell(r, c))
                                 for c in range(C)), suffix, buf_type, r, elem))
           line('            else {%s }' % ''.join(
-              ' __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, '
-              'out_tile[%d][%d]), rs, st_col%d ? lane_byte + %d : 0xfffffff0u, '
-              '(unsigned)(%d * W * %d), 0);' % (r, c, c, c * elem, r, elem)
+              ' __builtin_amdgcn_raw_buffer_store_b32(%s_bits('
+              '%s), rs, st_col%d ? lane_byte + %d : 0xfffffff0u, '
+              '(unsigned)(%d * W * %d), 0);' % (name, out_cell(r, c), c, c * elem, r, elem)
               for c in range(C)))
           line('          }')
         line('        }')
       line('      }')
     line('    }')
-    line('    soda_block_barrier();')
+    line('    %s();' % ('soda_lds_barrier' if ring else 'soda_block_barrier'))
   line('  }')
   line('}')
   line('')
@@ -348,6 +507,9 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('GLOBAL WG_SIZE(%d)%s void %s(soda_hip_args a) {' % (G * LANES, occupancy, name))
   line('  __attribute__((shared)) %s edges[%d][%d][%d][%d][%d];' % (
       T, max(1, len(publishers)), slots, G + 2, edge_rows, LANES * C))
+  if ring:
+    line('  __attribute__((shared)) %s in_ring[%d][%d][%d][%d];' % (T, ring, G, R,
+                                                                   LANES * C))
   line('  const int lane = lane_id();')
   line('  const int wave = __builtin_amdgcn_readfirstlane('
        '__builtin_amdgcn_workitem_id_x() >> 6);')
@@ -382,12 +544,14 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('  i64 wy = yb;')
   line('  if (wy + %d > a.dims[1]) wy = a.dims[1] - %d;' % (TR, TR))
   line('  if (wy < 0) wy = 0;')
-  line('  %s_band(a, xs, yb, wx, wy, z0, z1, wave, lane, edges);' % name)
+  line('  %s_band(a, xs, yb, wx, wy, z0, z1, wave, lane, edges, %s);'
+       % (name, 'in_ring' if ring else 'nullptr'))
   line('}')
   entry = dict(name=name, kind='fused', depth=depth, stage=-1,
                block=[G * LANES, 1, 1], tile=[w_out, r_out, chunk_planes, 1],
                origin_align=C, fill_rows=L + lo[2], cols=C, rows=R, stack=G,
                prefetch=prefetch, period=period, est_vgprs=est_vgprs, w_out=w_out,
-               r_out=r_out, lds_bytes=lds_bytes, xcd_tiles=int(bool(xcd_tiles)),
+               r_out=r_out, lds_bytes=lds_bytes + ring_bytes, ring=ring, pairs=pairs,
+               xcd_tiles=int(bool(xcd_tiles)),
                min_extent=[LANES * C, TR])
   return '\n'.join(o) + '\n', entry

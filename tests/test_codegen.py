@@ -213,6 +213,34 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   assert max(k['depth'] for k in table) == 2
 
 
+def test_3d_block_form_options_pairs_and_ring(tmp_path):
+  """Experimental options of the block form: packed pair-rows and
+  the per-wavefront LDS ring fed by LDS-direct loads.  A ring kernel waits with a
+  COUNTED vmcnt, so it must issue the same number of stores every step and must
+  not contain a release fence at its barrier."""
+  spec = specmod.spec_from_stencil(frontend.load(
+      os.path.join(SAMPLES, 'jacobi3d.soda'), iterate=4))
+  text, table = kernel.generate(spec, depths=[4], deep3d='blk', blk_prefetch=0,
+                                blk_ring=2, blk_pairs=1)
+  blk = [k for k in table if k.get('stack')]
+  assert len(blk) == 1 and blk[0]['ring'] == 2 and blk[0]['pairs'] == 1
+  assert blk[0]['lds_bytes'] == 80 * 1024 + 2 * 32 * 1024
+  body = text[text.index('jacobi3d_fused_k4b_band('):]
+  # one plane of ring loads (4 x 2 rows) and 2 steps x 8 stores behind the awaited one
+  assert '// vmcnt(20)' in body and '__builtin_amdgcn_global_load_lds' in body
+  assert 'soda_lds_barrier();' in body and 'soda_block_barrier();' not in body
+  assert 'pk2_shifted{' in body and 'pk_from_lane_below(' in body
+  assert 'if (z >= z0 && z < z1) {' not in body       # stores are never skipped
+  kernel.compile_to_code_object(text, str(tmp_path / 'k.hsaco'))
+  with pytest.raises(kernel_stream2d.NotFusable):      # ring and register prefetch
+    from soda_hip.codegen import kernel_stream3d_blk
+    kernel_stream3d_blk.emit(spec, 4, prefetch=1, ring=2)
+  # packing needs a plain float program: heat3d qualifies, an integer one does not
+  from soda_hip.codegen import kernel_stream3d_blk
+  _, entry = kernel_stream3d_blk.emit(spec_of('heat3d'), 4, stack=4, pairs=1)
+  assert entry['pairs'] == 1
+
+
 def test_pipeline_lags_match_the_reference_reuse_model():
   """jacobi2d: each level trails the previous by one row and keeps three rows
   (the reference's reuse chain for a 3-row window is 2 rows + 1)."""

@@ -257,6 +257,10 @@ def test_3d_wave_pipelined_forms_on_heat3d(options):
     ('jacobi3d', dict(deep3d='blk')),                      # 8 bands, prefetch 1
     ('jacobi3d', dict(deep3d='blk', blk_stack=4, blk_prefetch=0)),
     ('jacobi3d', dict(deep3d='blk', blk_stack=8, blk_rows=4, blk_prefetch=2)),
+    # packed pair-rows; input planes through per-wavefront LDS rings (counted waits)
+    ('jacobi3d', dict(deep3d='blk', blk_pairs=1)),
+    ('jacobi3d', dict(deep3d='blk', blk_prefetch=0, blk_ring=2)),
+    ('heat3d', dict(deep3d='blk', blk_stack=4, blk_prefetch=0, blk_pairs=1, blk_ring=2)),
     ('heat3d', dict(deep3d='blk', blk_stack=4))])
 def test_3d_block_form(app, options):
   """The block form of the depth-4 3-D kernel (kernel_stream3d_blk: all levels in
