@@ -173,8 +173,18 @@ class Stencil:
         raise SemanticError('`%s` is indexed with %d indices in a %d-D program'
                             % (stmt.name, len(stmt.ref.idx), self.dim))
       loads = []
-      for let in stmt.lets:
-        loads.extend(ex.loads_of(let.expr))
+      defined = set()
+      for let in list(stmt.lets) + [None]:
+        expr = stmt.expr if let is None else let.expr
+        # a variable is a `let` made earlier in the same statement (the reference
+        # dies with a KeyError on any other, core.py:116-120)
+        for node in ex.walk(expr):
+          if isinstance(node, ex.Var) and node.name not in defined:
+            raise SemanticError('`%s` uses undefined variable `%s`'
+                                % (stmt.name, node.name))
+        if let is not None:
+          defined.add(let.name)
+          loads.extend(ex.loads_of(let.expr))
       loads.extend(ex.loads_of(stmt.expr))
       if not loads:
         raise SemanticError('`%s` reads no tensor' % stmt.name)

@@ -212,6 +212,13 @@ def test_semantic_errors():
                    'output float: b(0,0) = a(0,0) + c(0,0)')
   with pytest.raises(SemanticError, match='undefined tensor'):
     frontend.loads(base + 'iterate: 1\ninput float: a(4,*)\noutput float: b(0,0) = z(0,0)')
+  # a variable must be a `let` made earlier in the statement (the reference dies
+  # with a KeyError in propagate_type, core.py:116-120)
+  with pytest.raises(SemanticError, match='undefined variable `lat`'):
+    frontend.loads(base + 'iterate: 1\ninput float: a(4,*)\noutput float: b(0,0) = a(0,0) + lat')
+  with pytest.raises(SemanticError, match='undefined variable `t`'):
+    frontend.loads(base + 'iterate: 1\ninput float: a(4,*)\n'
+                   'output float: s = t + a(0,0) t = a(1,0) b(0,0) = s + t')
 
 
 def test_overrides_like_sodac():
