@@ -334,3 +334,44 @@ def elem_sizes(spec):
   for n, i in idx.items():
     out[i] = specmod.ELEM_SIZE[types[n]]
   return out
+
+
+def cell_assignment(stage, target, load, emit, indent):
+  """Emits the C++ of ONE cell of a fused kernel: the stage's `let`s, then
+  `target = expression`, operands substituted by `load(tensor, rel)`.
+
+  An operand that comes from a neighbouring LANE (from_lane_below / from_lane_above:
+  DPP) must be read with every lane active: inside the right-hand side of `&&` or
+  `||` it would be read only by the lanes that get there, and a lane whose
+  neighbour took the other way would receive 0 instead of the neighbour's value.
+  Expressions that short-circuit therefore get their lane-crossing operands
+  evaluated first, into temporaries (found by tests/random_programs.py:
+  operator_program; the per-stage kernels read memory and are not concerned)."""
+  texts = [let['expr'] for let in stage['lets']] + [stage['expr']]
+  hoisted = []
+  if any('&&' in t or '||' in t for t in texts):
+    seen = {}
+    plain = load
+
+    def load(tensor, rel):      # noqa: F811 - the hoisting wrapper
+      text = plain(tensor, rel)
+      if 'from_lane' not in text:
+        return text
+      if text not in seen:
+        seen[text] = 'soda_lane%d' % len(seen)
+        hoisted.append('const auto %s = %s;' % (seen[text], text))
+      return seen[text]
+  lets = [(builtin_type(let['c_type']), let['name'],
+           specmod.substitute_loads(device_expr(let['expr']), load))
+          for let in stage['lets']]
+  value = specmod.substitute_loads(device_expr(stage['expr']), load)
+  if not lets and not hoisted:
+    emit('%s%s = %s;' % (indent, target, value))
+    return
+  emit(indent + '{')
+  for text in hoisted:
+    emit('%s  %s' % (indent, text))
+  for ctype, name, text in lets:
+    emit('%s  const %s %s = %s;' % (indent, ctype, name, text))
+  emit('%s  %s = %s;' % (indent, target, value))
+  emit(indent + '}')

@@ -27,7 +27,7 @@ Cost model per cell-update (jacobi2d): 5 VALU lane-ops, 8/depth bytes of HBM.
 """
 
 from . import spec as specmod
-from .kernel_common import builtin_type, device_expr, tensor_index
+from .kernel_common import builtin_type, cell_assignment, device_expr, tensor_index
 
 WAVES_PER_BLOCK = 4
 LANES = 64
@@ -321,18 +321,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
             return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, c)
           target = ('out_row[%d]' % c) if inst.final else \
               '%s[%d][%d]' % (inst.ident, slot(inst, u, 0), c)
-          if stage['lets']:
-            emit_line('      {')
-            for let in stage['lets']:
-              emit_line('        const %s %s = %s;' % (
-                  builtin_type(let['c_type']), let['name'],
-                  specmod.substitute_loads(device_expr(let['expr']), load)))
-            emit_line('        %s = %s;' % (target, specmod.substitute_loads(
-                device_expr(stage['expr']), load)))
-            emit_line('      }')
-          else:
-            emit_line('      %s = %s;' % (target, specmod.substitute_loads(
-                device_expr(stage['expr']), load)))
+          cell_assignment(stage, target, load, emit_line, '      ')
         if inst.final:
           emit_line('      {  // store row head+%d-%d' % (u, L))
           emit_line('        const i64 y = head + %d;' % (u - L))

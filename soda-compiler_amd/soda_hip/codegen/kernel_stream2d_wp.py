@@ -32,7 +32,7 @@ single-wave form.
 import re
 
 from . import spec as specmod
-from .kernel_common import builtin_type, device_expr, tensor_index
+from .kernel_common import builtin_type, cell_assignment, device_expr, tensor_index
 from .kernel_stream2d import LANES, Instance, NotFusable, geometry, kernel_name
 
 
@@ -407,18 +407,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
             return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, c)
           target = ('out_row[%d]' % c) if direct else \
               '%s[%d][%d]' % (inst.ident, slot(inst, u, 0), c)
-          if stage['lets']:
-            line('        {')
-            for let in stage['lets']:
-              line('          const %s %s = %s;' % (
-                  builtin_type(let['c_type']), let['name'],
-                  specmod.substitute_loads(device_expr(let['expr']), load)))
-            line('          %s = %s;' % (target, specmod.substitute_loads(
-                device_expr(stage['expr']), load)))
-            line('        }')
-          else:
-            line('        %s = %s;' % (target, specmod.substitute_loads(
-                device_expr(stage['expr']), load)))
+          cell_assignment(stage, target, load, line, '        ')
         if inst.role == 'lds_out' and pairs:
           for q in range(pieces):
             line('        { soda_f4 v;%s *(soda_f4*)&handoff[%d][%d][%d][%d][lane * 4] = v; }' % (

@@ -21,7 +21,7 @@ VGPRs, two waves per SIMD, and HBM sees (4/0.73 + 4)/2 = 4.7 B per update
 instead of 8.
 """
 from . import spec as specmod
-from .kernel_common import builtin_type, device_expr, tensor_index
+from .kernel_common import builtin_type, cell_assignment, device_expr, tensor_index
 from .kernel_stream2d import (LANES, WAVES_PER_BLOCK, NotFusable,
                               build_pipeline)
 
@@ -217,18 +217,7 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, max_period=1
             return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, r, c)
           target = ('out_tile[%d][%d]' % (r, c)) if inst.final else \
               '%s[%d][%d][%d]' % (inst.ident, slot(inst, u, 0), r, c)
-          if stage['lets']:
-            line('      {')
-            for let in stage['lets']:
-              line('        const %s %s = %s;' % (
-                  builtin_type(let['c_type']), let['name'],
-                  specmod.substitute_loads(device_expr(let['expr']), load)))
-            line('        %s = %s;' % (target, specmod.substitute_loads(
-                device_expr(stage['expr']), load)))
-            line('      }')
-          else:
-            line('      %s = %s;' % (target, specmod.substitute_loads(
-                device_expr(stage['expr']), load)))
+          cell_assignment(stage, target, load, line, '      ')
       if inst.final:
         line('      {  // store plane head+%d-%d' % (u, L))
         line('        const i64 z = head + %d;' % (u - L))

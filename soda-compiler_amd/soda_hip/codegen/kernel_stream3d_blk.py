@@ -38,7 +38,7 @@ Scope: one input, one output, 4-byte elements, x offsets within C columns,
 y offsets within R rows.
 """
 from . import spec as specmod
-from .kernel_common import builtin_type, device_expr, tensor_index
+from .kernel_common import builtin_type, cell_assignment, device_expr, tensor_index
 from .kernel_stream2d import LANES, Instance, NotFusable
 from .kernel_stream2d_wp import packable
 from .kernel_stream3d import kernel_name
@@ -436,18 +436,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
             return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, r, c)
           target = ('out_tile[%d][%d]' % (r, c)) if inst.final else \
               '%s[%d][%d][%d]' % (inst.ident, slot(inst, u, 0), r, c)
-          if stage['lets']:
-            line('        {')
-            for let in stage['lets']:
-              line('          const %s %s = %s;' % (
-                  builtin_type(let['c_type']), let['name'],
-                  specmod.substitute_loads(device_expr(let['expr']), load)))
-            line('          %s = %s;' % (target, specmod.substitute_loads(
-                device_expr(stage['expr']), load)))
-            line('        }')
-          else:
-            line('        %s = %s;' % (target, specmod.substitute_loads(
-                device_expr(stage['expr']), load)))
+          cell_assignment(stage, target, load, line, '        ')
       if inst.up or inst.down:
         publish(inst, u, slot(inst, u, 0))
       if inst.final and ring:

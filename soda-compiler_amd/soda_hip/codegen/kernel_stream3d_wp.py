@@ -20,7 +20,7 @@ and the last instance of the previous group; anything else keeps the
 single-wave form.
 """
 from . import spec as specmod
-from .kernel_common import builtin_type, device_expr, tensor_index
+from .kernel_common import builtin_type, cell_assignment, device_expr, tensor_index
 from .kernel_stream2d import LANES, NotFusable
 from .kernel_stream2d_wp import build_groups, packable
 from .kernel_stream3d import kernel_name
@@ -425,18 +425,7 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
               return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, r, c)
             target = ('out_tile[%d][%d]' % (r, c)) if direct else \
                 '%s[%d][%d][%d]' % (inst.ident, slot(inst, u, 0), r, c)
-            if stage['lets']:
-              line('        {')
-              for let in stage['lets']:
-                line('          const %s %s = %s;' % (
-                    builtin_type(let['c_type']), let['name'],
-                    specmod.substitute_loads(device_expr(let['expr']), load)))
-              line('          %s = %s;' % (target, specmod.substitute_loads(
-                  device_expr(stage['expr']), load)))
-              line('        }')
-            else:
-              line('        %s = %s;' % (target, specmod.substitute_loads(
-                  device_expr(stage['expr']), load)))
+            cell_assignment(stage, target, load, line, '        ')
         line('        }')
         if inst.role == 'lds_out' and pairs:
           for q in range(RP):

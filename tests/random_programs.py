@@ -87,7 +87,80 @@ def random_program(rng, seed):
 
 
 
-def program_set(n_plain=40, n_deep=16):
+def operator_program(rng, seed):
+  """Integer (and a few float-compare) programs over the operators the arithmetic
+  generator above never emits: % & | ^ comparisons && || unary - ~ !, hexadecimal,
+  octal and suffixed literals, casts between widths.  Every window contains the
+  store point, so the reference's own CPU loops have a defined answer."""
+  dim = 3 if rng.random() < 0.2 else 2
+  dtype = str(rng.choice(['uint16', 'int32', 'uint8', 'int16', 'uint32', 'int64',
+                          'int8', 'uint64']))
+  other = str(rng.choice(['int32', 'uint16', 'int16', 'uint8']))
+  iterate = int(rng.integers(1, 4))
+  reach = 2 if dim == 2 else 1
+  lines = ['kernel: ops%d' % seed, 'burst width: 512', 'unroll factor: 2',
+           'iterate: %d' % iterate,
+           'input %s: a(%s, *)' % (dtype, ', '.join(['32'] * (dim - 1)))]
+
+  def ref(name, centre=False):
+    idx = [0] * dim if centre else [int(rng.integers(-reach, reach + 1))
+                                    for _ in range(dim)]
+    return '%s(%s)' % (name, ', '.join(map(str, idx)))
+
+  def literal():
+    return str(rng.choice(['1', '2', '3', '5', '7', '0x0f', '0x3', '017', '3u', '6l',
+                           '0xffu', '9']))
+
+  def term(names):
+    n = str(rng.choice(names))
+    r = rng.random()
+    if r < 0.15:
+      return '(%s %% %s)' % (ref(n), str(rng.choice(['3', '5', '7', '0x10'])))
+    if r < 0.30:
+      return '(%s & %s)' % (ref(n), literal())
+    if r < 0.40:
+      return '(%s | %s)' % (ref(n), ref(str(rng.choice(names))))
+    if r < 0.50:
+      return '(%s ^ %s)' % (ref(n), ref(str(rng.choice(names))))
+    if r < 0.60:
+      return '(%s %s %s)' % (ref(n), str(rng.choice(['<', '<=', '>', '>=', '==', '!='])),
+                             ref(str(rng.choice(names))))
+    if r < 0.68:
+      return '(%s > %s && %s != %s)' % (ref(n), literal(), ref(n), literal())
+    if r < 0.74:
+      return '(%s < %s || %s == %s)' % (ref(n), literal(), ref(str(rng.choice(names))),
+                                        literal())
+    if r < 0.80:
+      return '(-%s)' % ref(n)
+    if r < 0.86:
+      return '(~%s & 0xff)' % ref(n)
+    if r < 0.90:
+      return '(!%s)' % ref(n)
+    if r < 0.95:
+      return '%s(%s) * %s' % (other, ref(n), literal())
+    return '%s / %s' % (ref(n), str(rng.choice(['2', '3', '4'])))
+
+  def expression(names):
+    parts = [ref(str(rng.choice(names)), centre=True)]     # the store point is read
+    parts += [term(names) for _ in range(int(rng.integers(2, 5)))]
+    text = parts[0]
+    for t in parts[1:]:
+      text += str(rng.choice([' + ', ' - ', ' + '])) + t
+    return text
+
+  names = ['a']
+  if rng.random() < 0.5:
+    lines.append('local %s: m(%s) = %s' % (other, ', '.join(['0'] * dim),
+                                           expression(names)))
+    names.append('m')
+  use = expression(names)
+  if 'm' in names and 'm(' not in use:
+    use += ' + ' + ref('m', centre=True)
+  lines.append('output %s: out(%s) = %s' % (dtype, ', '.join(['0'] * dim), use))
+  return '\n'.join(lines) + '\n', dim, dtype, iterate
+
+
+def program_set(n_plain=40, n_deep=16, n_ops=16):
   """[(key, text, dim, iterate, shape)] - the programs of the GPU random tests."""
   out = []
   for seed in range(n_plain):
@@ -103,6 +176,10 @@ def program_set(n_plain=40, n_deep=16):
     deep = int(rng.integers(8, 21))
     text = text.replace('iterate: %d\n' % iterate, 'iterate: %d\n' % deep)
     out.append(('deep%d' % seed, text, dim, deep))
+  for seed in range(n_ops):
+    rng = np.random.default_rng(9000 + seed)
+    text, dim, dtype, iterate = operator_program(rng, seed)
+    out.append(('ops%d' % seed, text, dim, iterate))
   return out
 
 

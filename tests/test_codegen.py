@@ -241,6 +241,31 @@ def test_3d_block_form_options_pairs_and_ring(tmp_path):
   assert entry['pairs'] == 1
 
 
+def test_lane_crossing_operands_leave_short_circuit_expressions():
+  """`a(-1,0) < 5 || a(1,0) == 9` in a fused kernel: the x-neighbours come from other
+  lanes by DPP, which must run with every lane active - not inside the right-hand
+  side of `||`, where a lane whose neighbour went the other way would read 0.  The
+  generators evaluate such operands first (kernel_common.cell_assignment); programs
+  without && / || keep the operands inside the expression."""
+  text = '''
+    kernel: shortcut
+    burst width: 512
+    unroll factor: 1
+    iterate: 2
+    input int32: a(32, *)
+    output int32: b(0, 0) = a(0, 0) + (a(-1, 0) < 5 || a(1, 0) == 9) + (a(0, 1) > 3 && a(-1, -1) != 7)
+  '''
+  spec = specmod.spec_from_stencil(frontend.loads(text))
+  src, table = kernel.generate(spec)
+  assert [k['depth'] for k in table if k['kind'] == 'fused'] == [1, 2]
+  fused = src[src.index('shortcut_fused_k1_strip'):]
+  assignments = [l for l in fused.splitlines() if ' || ' in l]
+  assert assignments and all('from_lane' not in l for l in assignments)
+  assert 'const auto soda_lane0 = from_lane_' in fused
+  plain, _ = kernel.generate(spec_of('jacobi2d'))
+  assert 'soda_lane' not in plain and 'from_lane_below(' in plain
+
+
 def test_pipeline_lags_match_the_reference_reuse_model():
   """jacobi2d: each level trails the previous by one row and keeps three rows
   (the reference's reuse chain for a 3-row window is 2 rows + 1, SURVEY 8a-9)."""

@@ -2,7 +2,9 @@
 (hiprtc) and compared bit for bit with the CPU oracle: asymmetric and one-sided
 windows, negative-only offsets (stages that run AHEAD of their parents in the
 streaming pipeline), fan-in and fan-out DAGs, `let`s, casts, integer division,
-several inputs, 2-D and 3-D, fused and per-stage kernels, every depth split."""
+several inputs, 2-D and 3-D, fused and per-stage kernels, every depth split; and
+integer programs over the remaining operators of the grammar (% & | ^ comparisons
+&& || unary - ~ !, non-decimal literals)."""
 import json
 import os
 import tempfile
@@ -76,6 +78,17 @@ def run_case(key, shape, rng):
 def test_random_program(seed):
   rng = np.random.default_rng(1000 + seed)
   key = 'plain%d' % seed
+  run_case(key, (41, 333) if PROGRAMS[key]['dim'] == 2 else (19, 23, 150), rng)
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_random_operator_program(seed):
+  """Integer programs over % & | ^, comparisons, && ||, unary - ~ !, hexadecimal /
+  octal / suffixed literals and casts between widths (tests/random_programs.py:
+  operator_program), all 16 with a fixture from the reference's own CPU loops."""
+  rng = np.random.default_rng(9000 + seed)
+  key = 'ops%d' % seed
+  assert key in REFERENCE
   run_case(key, (41, 333) if PROGRAMS[key]['dim'] == 2 else (19, 23, 150), rng)
 
 
