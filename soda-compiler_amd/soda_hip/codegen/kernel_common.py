@@ -34,8 +34,13 @@ _DOUBLE_UNARY = ('cos sin tan acos asin atan cosh sinh tanh acosh asinh atanh ex
                  'ceil floor trunc round rint nearbyint fabs sqrt').split()
 _DOUBLE_BINARY = ('atan2 pow hypot fmod remainder copysign nextafter fdim fmax '
                   'fmin').split()
+# (double, int) -> double; double -> integer: as <math.h> declares them globally
+_DOUBLE_INT = ('ldexp', 'scalbn', 'scalbln')
+_TO_INTEGER = {'ilogb': 'int', 'lround': 'long', 'llround': 'long long',
+               'lrint': 'long', 'llrint': 'long long'}
 _CALL_RE = re.compile(r'\b(%s)\s*\(' % '|'.join(
-    _DOUBLE_UNARY + _DOUBLE_BINARY + ['fma', 'abs', 'min', 'max', 'select']))
+    _DOUBLE_UNARY + _DOUBLE_BINARY + list(_DOUBLE_INT) + sorted(_TO_INTEGER) +
+    ['fma', 'abs', 'min', 'max', 'select']))
 
 
 def builtin_type(c_type):
@@ -79,6 +84,18 @@ def math_wrappers(names):
                  '__ocml_%s_f64(double, double);' % name)
       out.append('DEV double soda_fn_%s(double x, double y) '
                  '{ return __ocml_%s_f64(x, y); }' % (name, name))
+    elif name in _DOUBLE_INT:
+      out.append('extern "C" __attribute__((device)) double __ocml_ldexp_f64(double, int);')
+      out.append('DEV double soda_fn_%s(double x, %s n) { return __ocml_ldexp_f64(x, '
+                 '(int)(n < -100000 ? -100000 : (n > 100000 ? 100000 : n))); }'
+                 % (name, 'long' if name == 'scalbln' else 'int'))
+    elif name == 'ilogb':
+      out.append('extern "C" __attribute__((device)) int __ocml_ilogb_f64(double);')
+      out.append('DEV int soda_fn_ilogb(double x) { return __ocml_ilogb_f64(x); }')
+    elif name in _TO_INTEGER:
+      out.append('DEV %s soda_fn_%s(double x) { return (%s)__builtin_%s(x); }' % (
+          _TO_INTEGER[name], name, _TO_INTEGER[name],
+          'round' if 'round' in name else 'rint'))
     elif name == 'fma':
       out.append('DEV double soda_fn_fma(double x, double y, double z) '
                  '{ return __builtin_fma(x, y, z); }')
