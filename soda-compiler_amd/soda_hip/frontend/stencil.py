@@ -315,18 +315,59 @@ class Stencil:
     """Every stage clone of every iteration in execution order, named like the
     reference names them: dicts with name, stage, iteration, parent renames and
     the loop bounds of the reference's CPU golden loops (host.py:1082-1091)."""
+    all_boxes = self.iteration_boxes()
     out = []
-    for k, boxes in enumerate(self.iteration_boxes()):
-      for name in self.order:
-        stage = self.stages[name]
-        box = boxes[name]
-        out.append(dict(
-            name=self.name_in_iter(name, k), base=name, iteration=k,
-            stage=stage,
-            rename={p: self.name_in_iter(p, k) for p in stage.parents()},
-            loop_lo=tuple(-v for v in box.lo), loop_hi_margin=tuple(box.hi),
-            is_output=(name in self.output_names and k == self.iterate - 1)))
+    for k, name in self.unrolled_order():
+      stage = self.stages[name]
+      box = all_boxes[k][name]
+      out.append(dict(
+          name=self.name_in_iter(name, k), base=name, iteration=k,
+          stage=stage,
+          rename={p: self.name_in_iter(p, k) for p in stage.parents()},
+          loop_lo=tuple(-v for v in box.lo), loop_hi_margin=tuple(box.hi),
+          is_output=(name in self.output_names and k == self.iterate - 1)))
     return out
+
+  def unrolled_order(self):
+    """(iteration, stage) pairs in the order of the reference's
+    `chronological_tensors` (core.py:407-554): ONE breadth-first walk over the graph
+    of all iterations' clones, a clone entering when all its parents have.  For a
+    single chain this is iteration after iteration in `self.order`; with several
+    outputs the walk interleaves differently from the second iteration on (the
+    queue carries over).  The run time executes iteration after iteration - any
+    topological order computes the same values."""
+    def parents_of(k, name):
+      out = []
+      for p in self.stages[name].parents():
+        if p in self.input_names:
+          if k == 0:
+            out.append(('input', p))
+          else:      # the matching output of the previous iteration
+            out.append((k - 1, self.output_names[self.input_names.index(p)]))
+        else:
+          out.append((k, p))
+      return out
+    nodes = [(k, name) for k in range(self.iterate) for name in self.stages]
+    children = collections.OrderedDict((('input', n), []) for n in self.input_names)
+    for node in nodes:
+      children[node] = []
+    parents = {}
+    for node in nodes:
+      parents[node] = parents_of(*node)
+      for p in parents[node]:
+        if node not in children[p]:
+          children[p].append(node)
+    seen = set(('input', n) for n in self.input_names)
+    queue = collections.deque(('input', n) for n in self.input_names)
+    order = []
+    while queue:
+      for child in children[queue.popleft()]:
+        if child not in seen and all(p in seen for p in parents[child]):
+          seen.add(child)
+          order.append(child)
+          queue.append(child)
+    assert len(order) == len(nodes), (order, nodes)
+    return order
 
   def is_float(self):
     return is_float(self.input_types[0])

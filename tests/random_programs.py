@@ -160,7 +160,70 @@ def operator_program(rng, seed):
   return '\n'.join(lines) + '\n', dim, dtype, iterate
 
 
-def program_set(n_plain=40, n_deep=16, n_ops=16):
+def structure_program(rng, seed):
+  """Programs that stress the STRUCTURE the other generators keep small: three
+  inputs, windows reaching up to 4 cells, up to seven stages, several outputs
+  (with `iterate` > 1 when inputs and outputs pair up), 3-D with two inputs, a local
+  that only another local reads.  Every window contains the store point."""
+  dim = 3 if rng.random() < 0.3 else 2
+  dtype = str(rng.choice(['float', 'float', 'int32', 'double', 'uint16']))
+  floaty = dtype in ('float', 'double')
+  n_inputs = int(rng.integers(1, 4))
+  n_outputs = int(rng.integers(1, 3))
+  n_locals = int(rng.integers(1, 6))
+  iterate = int(rng.integers(2, 6)) if n_inputs == n_outputs else 1
+  reach = int(rng.integers(1, 5)) if dim == 2 else int(rng.integers(1, 3))
+  ins = ['in%d' % i for i in range(n_inputs)]
+  lines = ['kernel: st%d' % seed, 'burst width: 512', 'unroll factor: 4',
+           'iterate: %d' % iterate]
+  tile = ', '.join(['64'] * (dim - 1))
+  for i, n in enumerate(ins):      # only the LAST input may carry the tile
+    lines.append('input %s: %s(%s, *)' % (dtype, n, tile) if i == n_inputs - 1
+                 else 'input %s: %s' % (dtype, n))
+
+  def ref(name, centre=False):
+    idx = [0] * dim if centre else [int(rng.integers(-reach, reach + 1))
+                                    for _ in range(dim)]
+    return '%s(%s)' % (name, ', '.join(map(str, idx)))
+
+  def literal():
+    return str(rng.choice(['0.25f', '0.5f', '0.125f', '2.0f'] if floaty
+                          else ['1', '2', '3']))
+
+  def expression(names, must):
+    parts = [ref(str(rng.choice(names)), centre=True)]
+    pool = list(must) + [str(rng.choice(names)) for _ in range(int(rng.integers(1, 4)))]
+    for n in pool:
+      t = ref(n)
+      if rng.random() < 0.4:
+        t = '%s * %s' % (t, literal())
+      parts.append(t)
+    text = parts[0]
+    for t in parts[1:]:
+      text += str(rng.choice([' + ', ' - ', ' + '])) + t
+    if floaty and rng.random() < 0.5:
+      text = '(%s) * %s' % (text, literal())
+    return text
+
+  names = list(ins)
+  unused = list(ins)
+  for k in range(n_locals):
+    name = 'loc%d' % k
+    must = [unused.pop(0)] if unused else []
+    lines.append('local %s: %s(%s) = %s' % (dtype, name, ', '.join(['0'] * dim),
+                                            expression(names, must)))
+    names.append(name)
+    unused.append(name)
+  for k in range(n_outputs):
+    share = [unused.pop(0) for _ in range((len(unused) + n_outputs - k - 1)
+                                          // (n_outputs - k))] if unused else []
+    lines.append('output %s: out%s(%s) = %s' % (
+        dtype, '' if k == 0 else str(k), ', '.join(['0'] * dim),
+        expression(names, share)))
+  return '\n'.join(lines) + '\n', dim, dtype, iterate
+
+
+def program_set(n_plain=40, n_deep=16, n_ops=16, n_struct=16):
   """[(key, text, dim, iterate, shape)] - the programs of the GPU random tests."""
   out = []
   for seed in range(n_plain):
@@ -180,6 +243,10 @@ def program_set(n_plain=40, n_deep=16, n_ops=16):
     rng = np.random.default_rng(9000 + seed)
     text, dim, dtype, iterate = operator_program(rng, seed)
     out.append(('ops%d' % seed, text, dim, iterate))
+  for seed in range(n_struct):
+    rng = np.random.default_rng(12000 + seed)
+    text, dim, dtype, iterate = structure_program(rng, seed)
+    out.append(('struct%d' % seed, text, dim, iterate))
   return out
 
 
