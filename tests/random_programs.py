@@ -223,7 +223,48 @@ def structure_program(rng, seed):
   return '\n'.join(lines) + '\n', dim, dtype, iterate
 
 
-def program_set(n_plain=40, n_deep=16, n_ops=16, n_struct=16):
+def cube_program(rng, seed):
+  """3-D iteration chains for the deep 3-D kernels (single-wave depth 2, wave-
+  pipelined and block-form depth 4): one input, one output, optionally a local in
+  between, 4..13 iterations, windows inside {-1,0,1}^3 INCLUDING diagonals (a read
+  that leaves the band in y and the plane in z at once)."""
+  dtype = str(rng.choice(['float', 'float', 'float', 'int32']))
+  floaty = dtype == 'float'
+  iterate = int(rng.integers(4, 14))
+  lines = ['kernel: cube%d' % seed, 'burst width: 512', 'unroll factor: 2',
+           'iterate: %d' % iterate, 'input %s: a(32, 32, *)' % dtype]
+
+  def offsets(n):
+    seen = {(0, 0, 0)}
+    while len(seen) < n:
+      seen.add(tuple(int(v) for v in rng.integers(-1, 2, size=3)))
+    rest = sorted(seen - {(0, 0, 0)})
+    rng.shuffle(rest)
+    return [(0, 0, 0)] + [tuple(o) for o in rest]
+
+  def expression(name):
+    terms = []
+    for o in offsets(int(rng.integers(4, 10))):
+      t = '%s(%d, %d, %d)' % ((name,) + o)
+      if rng.random() < 0.3:
+        t += ' * %s' % (str(rng.choice(['0.5f', '0.25f', '2.0f'])) if floaty
+                        else str(rng.choice(['2', '3'])))
+      terms.append(t)
+    text = terms[0]
+    for t in terms[1:]:
+      text += str(rng.choice([' + ', ' + ', ' - '])) + t
+    scale = str(rng.choice(['0.125f', '0.0625f', '0.2f'])) if floaty else '1'
+    return '(%s) * %s' % (text, scale) if floaty else text
+
+  src = 'a'
+  if rng.random() < 0.35:
+    lines.append('local %s: m(0, 0, 0) = %s' % (dtype, expression('a')))
+    src = 'm'
+  lines.append('output %s: out(0, 0, 0) = %s' % (dtype, expression(src)))
+  return '\n'.join(lines) + '\n', 3, dtype, iterate
+
+
+def program_set(n_plain=40, n_deep=16, n_ops=16, n_struct=16, n_cube=12):
   """[(key, text, dim, iterate, shape)] - the programs of the GPU random tests."""
   out = []
   for seed in range(n_plain):
@@ -247,6 +288,10 @@ def program_set(n_plain=40, n_deep=16, n_ops=16, n_struct=16):
     rng = np.random.default_rng(12000 + seed)
     text, dim, dtype, iterate = structure_program(rng, seed)
     out.append(('struct%d' % seed, text, dim, iterate))
+  for seed in range(n_cube):
+    rng = np.random.default_rng(15000 + seed)
+    text, dim, dtype, iterate = cube_program(rng, seed)
+    out.append(('cube%d' % seed, text, dim, iterate))
   return out
 
 

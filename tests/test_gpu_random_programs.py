@@ -30,7 +30,7 @@ with open(os.path.join(GOLDEN, 'random_manifest.json')) as f:
 SCRATCH = tempfile.mkdtemp(prefix='soda_oracle_')      # not oracle/_build
 
 
-def run_case(key, shape, rng):
+def run_case(key, shape, rng, **gen):
   """One random program through the HIP back end (hiprtc), every depth split:
   (a) on the inputs of the REFERENCE's own run of this program, against the
   reference's result (tests/golden/random.<key>.npz, made by `make_golden.py
@@ -41,7 +41,7 @@ def run_case(key, shape, rng):
   text, iterate = entry['text'], entry['iterate']
   stencil = frontend.loads(text)
   spec = specmod.spec_from_stencil(stencil)
-  src, table = kernel.generate(spec)
+  src, table = kernel.generate(spec, **gen)
   prog = host.open_program(source=src, spec=spec)
   fused = [k['depth'] for k in table if k['kind'] == 'fused']
   cases = []
@@ -128,6 +128,27 @@ def test_random_structure_program(seed):
       axis = spec['dim'] - 1 - d
       shape[axis] = max(shape[axis], hi[d] - lo[d] + 20)
   run_case(key, tuple(shape), rng)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_3d_chain_program(seed):
+  """3-D iteration chains with diagonal reads, 4..13 iterations: the single-wave,
+  wave-pipelined and block-form deep 3-D kernels as the generator picks them
+  (tests/random_programs.py: cube_program), all 12 with a reference fixture."""
+  rng = np.random.default_rng(15000 + seed)
+  key = 'cube%d' % seed
+  assert key in REFERENCE
+  table = run_case(key, (70, 90, 200), rng)
+  assert any(k['kind'] == 'fused' for k in table)
+  if any(k.get('stack') for k in table):
+    # the block form ALONE (the scheduler may have preferred the wave-pipelined
+    # kernel above), plain and with packed pair-rows where the program allows
+    table = run_case(key, (70, 90, 200), np.random.default_rng(15100 + seed),
+                     deep3d='blk')
+    assert [bool(k.get('stack')) for k in table if k['depth'] == 4] == [True]
+    if PROGRAMS[key]['text'].count('float') and 'local' not in PROGRAMS[key]['text']:
+      run_case(key, (70, 90, 200), np.random.default_rng(15200 + seed),
+               deep3d='blk', blk_pairs=1)
 
 
 @pytest.mark.parametrize('seed', range(int(os.environ.get('SODA_RANDOM_DEEP_SEEDS', '16'))))
