@@ -870,7 +870,9 @@ def test_output_that_feeds_another_output():
     ('jacobi2d', (1500, 611), 2, 12, 30), ('jacobi2d', (1500, 611), 3, 5, 17),
     ('jacobi2d', (1500, 611), 4, 24, 48), ('jacobi2d', (900, 1400), 2, 144, 300),
     ('jacobi3d', (130, 70, 96), 2, 8, 20), ('jacobi3d', (67, 45, 120), 3, 4, 13),
-    ('heat3d', (100, 64, 90), 2, 12, 24), ('hyper4d', (40, 14, 13, 33), 3, 2, 5)])
+    ('heat3d', (100, 64, 90), 2, 12, 24), ('hyper4d', (40, 14, 13, 33), 3, 2, 5),
+    # ghost zones of different depth below and above (2 rows up, 1 down per iteration)
+    ('skew2d', (1500, 611), 3, 12, 40), ('skew2d', (1100, 900), 4, 7, 21)])
 def test_slab_decomposition_with_the_hip_engine(app, dims, world, exchange, iterate):
   """The multi-GPU driver's slab logic (soda_hip.runtime.dist) run with the REAL
   kernels: all ranks emulated on this one GPU, ghost rows copied by hand where
@@ -889,7 +891,10 @@ def test_slab_decomposition_with_the_hip_engine(app, dims, world, exchange, iter
   zero = (tuple([0] * dim), tuple([0] * dim))
   margins_of = lambda k: zero if k == 0 else table[k - 1]
   engine = sdist.HipEngine(prog, torch)
-  plans = [sdist.SlabPlan(list(dims), r, world, 1, 1, exchange) for r in range(world)]
+  r_lo, r_hi = spec['radius']['lo'][-1], spec['radius']['hi'][-1]
+  plans = [sdist.SlabPlan(list(dims), r, world, r_lo, r_hi, exchange)
+           for r in range(world)]
+  assert (r_lo, r_hi) == ((2, 1) if app == 'skew2d' else (1, 1))
   dev = torch.device('cuda', 0)
   cur, nxt = [], []
   for p in plans:
