@@ -329,28 +329,39 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
     const double line = 128.0 / std::max(1, plan->prog.elem_size[0]);
     const double hx = std::max(0, desc.min_extent[0] - desc.tile[0]) + 0.75 * line;
     const double hy = std::max(0, desc.min_extent[1] - desc.tile[1]);
-    // Super-tiles are dealt whole, so a shape is only eligible if the busiest XCD
-    // gets no more workgroups than it holds at once where the plain deal fits the
-    // chip (jacobi3d 512^3, 9 x 21 x 4 tiles on 768 slots: 3 x 7 puts 105 tiles
-    // on four of the XCDs and 84 on the others - 500 us per launch against 379;
-    // 1 x 3 puts 96 on each - 351 us), or 3 % more than its even share otherwise.
+    // Which shapes are eligible (jacobi3d, depth-4 wave-pipelined kernel, one call
+    // each; `ids` = workgroup ids launched, padding included):
+    //   512^3, 9 x 21 x 4 = 756 tiles on 768 slots: plain deal 378 us, 3 x 1 338,
+    //     1 x 3 354, 2 x 1 (840 ids) 435, 1 x 2 (792 ids) 450, 3 x 7 (105 tiles on
+    //     four XCDs, 84 on the others) 500
+    //   440^3, 8 x 18 x 5 = 720: plain 223, 2 x 1 199, 4 x 1 189, 1 x 2 / 1 x 3 223
+    //   392^3, 7 x 16 x 6 = 672: plain 162, 2 x 1 / 4 x 1 (768 ids) 150 / 140
+    //   344^3, 6 x 14 x 9 = 756: plain 104, 3 x 1 97, 2 x 2 96, 4 x 1 (1008 ids) 140
+    //   264^3, 5 x 11 x 13 = 715: plain 63, 2 x 1 / 3 x 1 (864 ids) 83 / 77;
+    //     5 x 11 x 8 = 440: plain 56, 3 x 1 (66 tiles on the even XCDs, 44 on the odd) 67
+    // So: (1) a partial super-tile is padded with workgroups that exit at once, and
+    // that is harmless only while ALL ids fit the chip at once; (2) super-tiles are
+    // dealt whole, so the busiest XCD must stay within 3 % of its even share;
+    // (3) grouping along x is what pays (neighbours share 128-byte lines), along y
+    // hardly at all.
     const int64_t real = gx * gy * gz;
-    const int64_t slots = std::max<int64_t>(1, plan->resident_blocks[k] / 8);
+    const int64_t slots = std::max<int64_t>(8, plan->resident_blocks[k] / 8 * 8);
     const int64_t even = (real + 7) / 8;
-    const int64_t limit = even <= slots ? slots : even + even * 3 / 100;
+    const int64_t limit = even + std::max<int64_t>(1, even * 3 / 100);
     int best_sx = 1, best_sy = 1;
     double best = -1;
-    // (kernel_stream3d_wp asks for at most 3 tiles per super-tile, the block form
-    // for 1 = the plain deal.)  Larger groups cut the PMC read bytes further
-    // (jacobi3d x200: reads 2.5x -> 1.7x the written bytes with groups up to 24)
-    // but every one measured ran SLOWER (cfg5 6.2 -> 7.0-7.4 ms), also with the
-    // XCDs evenly loaded; 1 x 3 / 3 x 1 are neutral to 7 % faster per launch
+    // (the kernel names its largest group, soda_hip_kernel.xcd_tiles: 4 for
+    // kernel_stream3d_wp, 1 = the plain deal for the block form.)  Groups of 16-24
+    // tiles cut the PMC read bytes further (jacobi3d x200: reads 2.5x -> 1.7x the
+    // written bytes) but every one measured ran SLOWER (cfg5 6.2 -> 7.0-7.4 ms)
     int max_group = std::max(1, (int)desc.xcd_tiles);   // the kernel's own limit
     if (const char* env = tuning_env("SODA_HIP_XCD_GROUP")) max_group = std::max(1, atoi(env));
     for (int sx = 1; sx <= 8; ++sx)
       for (int sy = 1; sy <= 8; ++sy) {
         if (sx * sy > max_group) continue;
         const int64_t nsx = (gx + sx - 1) / sx, nsy = (gy + sy - 1) / sy;
+        const int64_t ids = (nsx * nsy * gz + 7) / 8 * 8 * sx * sy;
+        if (sx * sy > 1 && ids > (real <= slots ? slots : real + real * 3 / 100)) continue;
         // real tiles per XCD: super-tile g -> XCD g % 8; edge super-tiles are partial
         int64_t per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int64_t g = 0; g < nsx * nsy * gz; ++g) {
@@ -358,9 +369,9 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
           const int64_t ty = std::min<int64_t>(sy, gy - ((g / nsx) % nsy) * sy);
           per_xcd[g % 8] += tx * ty;
         }
-        if (*std::max_element(per_xcd, per_xcd + 8) > limit) continue;
+        if (sx * sy > 1 && *std::max_element(per_xcd, per_xcd + 8) > limit) continue;
         const double cost = (1 + hx / (std::min<int64_t>(sx, gx) * w)) *
-                            (1 + hy / (std::min<int64_t>(sy, gy) * r));
+                            (1 + 0.25 * hy / (std::min<int64_t>(sy, gy) * r));
         if (best < 0 || cost < best) { best = cost; best_sx = sx; best_sy = sy; }
       }
     if (const char* env = tuning_env("SODA_HIP_XCD_TILES")) {   // tuning: "SX,SY"

@@ -721,6 +721,6 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
                fill_rows=L + lo[2], cols=C, rows=R, prefetch=prefetch,
                period=period, est_vgprs=est_vgprs, w_out=w_out, r_out=r_out,
                groups=groups, lds_bytes=lds_bytes, split=split, loader=loader,
-               pairs=pairs, xcd_tiles=3 * int(bool(xcd_tiles)), buffer_io=int(bool(buffer_io)),
+               pairs=pairs, xcd_tiles=4 * int(bool(xcd_tiles)), buffer_io=int(bool(buffer_io)),
                min_extent=[LX * C, TR] if split == 2 else [0, 0])
   return '\n'.join(o) + '\n', entry

@@ -189,7 +189,7 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   assert 'edges[' in text and 'soda_block_barrier' in text
   k4 = [k for k in table if k['kind'] == 'fused' and k['depth'] == 4 and k.get('groups')]
   assert k4 and k4[0]['groups'] == 4 and k4[0]['block'] == [256, 1, 1]
-  assert k4[0]['xcd_tiles'] == 3 and k4[0]['buffer_io'] == 1
+  assert k4[0]['xcd_tiles'] == 4 and k4[0]['buffer_io'] == 1
   assert k4[0]['min_extent'] == [64, 32] and k4[0]['tile'][:2] == [56, 24]
   assert k4[0]['lds_bytes'] <= 64 * 1024
   assert 'v_permlane32_swap' in text or 'rows_across_halves' in text
