@@ -7,6 +7,7 @@ import os
 import pytest
 
 from soda_hip import frontend
+from soda_hip.codegen import spec as specmod
 from soda_hip.frontend import expr as ex
 from soda_hip.frontend.errors import SemanticError, SodaSyntaxError
 from soda_hip.frontend.types import c_type
@@ -119,6 +120,27 @@ def test_random_program_texts_are_the_committed_ones():
   assert sorted(now) == sorted(RANDOM_PROGRAMS)
   for key in now:
     assert now[key] == RANDOM_PROGRAMS[key]['text'], key
+
+
+def test_specs_equal_those_built_from_the_reference_stencil():
+  """tests/golden/plugin_specs.json: sha256 of the spec that the back end's plug-in
+  entry (`backend.to_spec`) builds from the REFERENCE's own `core.Stencil`, for the
+  hand-written extras and all random programs (written by
+  `tools/check_reference_plugin.py --write` under python3.9, next to the reference).
+  The own front end must arrive at the same spec, byte for byte: what the kernels
+  are generated from does not depend on which of the two analysed the program."""
+  import hashlib
+  with open(os.path.join(GOLDEN, 'plugin_specs.json')) as f:
+    digests = json.load(f)
+  assert len(digests) >= 100
+  for key, want in sorted(digests.items()):
+    family, name = key.split('.', 1)
+    if family == 'extra':
+      st = frontend.load(os.path.join(SAMPLES, 'extra', name + '.soda'))
+    else:
+      st = frontend.loads(RANDOM_PROGRAMS[name]['text'])
+    text = specmod.dumps(specmod.spec_from_stencil(st))
+    assert hashlib.sha256(text.encode()).hexdigest() == want, key
 
 
 def test_samples_all_parse():
