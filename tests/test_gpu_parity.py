@@ -971,6 +971,50 @@ def test_multi_process_slabs_on_one_gpu(tmp_path, app, dims, world, iterate, exc
   assert min(n_exchanges) >= -(-iterate // exchange)
 
 
+def test_bench_py_as_the_driver_launches_it_for_two_gpus():
+  """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py
+  --gpus 2 --steps K --warmup W`, the driver's command for N > 1, on this box's ONE
+  GPU: SODA_DIST_BACKEND=gloo lets two ranks share the device (RCCL refuses that),
+  everything else - slabs, ghost exchange inside the timed region, barrier and
+  max-over-ranks timing, the one JSON line of rank 0 - is the production path."""
+  import socket
+  import subprocess
+  import sys
+  from conftest import ROOT
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  r = subprocess.run(
+      [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
+       '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+       os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+       '--size', '4096', '3000', '--iterate', '120'],
+      capture_output=True, text=True, timeout=600,
+      env=dict(os.environ, SODA_DIST_BACKEND='gloo', OMP_NUM_THREADS='2'))
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+  assert len(lines) == 1, r.stdout[-2000:]
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1
+  assert d['metric'] == 'gcell_updates_per_s' and d['unit'] == 'Gcell-updates/s'
+  assert d['scaling'] == 'strong' and d['higher_is_better'] is True
+  assert d['vs_baseline'] is None and d['dtype'] == 'f32' and d['data'] == 'synthetic'
+  c = d['config']
+  assert c['dims'] == [4096, 3000] and c['iterate'] == 120
+  assert c['exchanges_per_step'] >= 1 and c['exchange_every'] >= 1
+  assert c['ghost_rows'] == [c['exchange_every'], c['exchange_every']]
+  # whole-job throughput on VALID updates of the whole grid, both ranks' rows
+  spec = gpu_util.load_spec('jacobi2d', iterate=120)
+  from soda_hip.codegen import spec as specmod
+  valid = specmod.valid_cells(spec, [4096, 3000], 120)
+  assert c['valid_cell_updates'] == valid
+  assert abs(d['value'] - valid / (d['ms_per_step'] * 1e-3) / 1e9) < 1e-6 * d['value']
+  rf = d['roofline']
+  assert rf['kernel'].startswith('jacobi2d_fused_k') and 0 < rf['frac'] < 1.5
+  assert 'cpu_baseline' not in d        # rank 0 at N = 1 only
+
+
 def test_denormals_signed_zeros_and_infinities():
   """IEEE corner cases: subnormal inputs (no flush-to-zero on either side),
   negative zeros, infinities (inf - inf = NaN must appear in the same cells)."""
