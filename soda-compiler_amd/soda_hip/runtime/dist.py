@@ -93,16 +93,23 @@ def exchange_ghosts(array, plan, dist, backend_ops=None):
   g_lo, g_hi, own = plan.ghost_lo, plan.ghost_hi, plan.own
   first_own = g_lo
   last_own = g_lo + own
+  # bytes are bytes: unsigned element types travel as the signed type of the same
+  # width (RCCL has no uint16 / uint32 / uint64)
+  signed = {'torch.uint16': 'int16', 'torch.uint32': 'int32', 'torch.uint64': 'int64'}
+  if str(array.dtype) in signed:
+    import torch
+    array = array.view(getattr(torch, signed[str(array.dtype)]))
+
+  def add(op, rows, peer):     # a one-sided window has nothing to ship one way:
+    if rows.shape[0] > 0:      # both sides skip that (empty) message
+      ops.append(dist.P2POp(op, rows, peer))
   if plan.has_lo:
     # lower neighbour: it needs our first send_down rows, we need its last rows
-    ops.append(dist.P2POp(dist.isend, array[first_own:first_own + plan.send_down],
-                          plan.rank - 1))
-    ops.append(dist.P2POp(dist.irecv, array[0:g_lo], plan.rank - 1))
+    add(dist.isend, array[first_own:first_own + plan.send_down], plan.rank - 1)
+    add(dist.irecv, array[0:g_lo], plan.rank - 1)
   if plan.has_hi:
-    ops.append(dist.P2POp(dist.isend, array[last_own - plan.send_up:last_own],
-                          plan.rank + 1))
-    ops.append(dist.P2POp(dist.irecv, array[last_own:last_own + g_hi],
-                          plan.rank + 1))
+    add(dist.isend, array[last_own - plan.send_up:last_own], plan.rank + 1)
+    add(dist.irecv, array[last_own:last_own + g_hi], plan.rank + 1)
   if ops:
     for req in dist.batch_isend_irecv(ops):
       req.wait()
