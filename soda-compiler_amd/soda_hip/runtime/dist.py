@@ -391,6 +391,9 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
       return run_slab(engine, plan, [a, b, c], args.iterate, margins_of, dist,
                       schedule=order)
 
+    # a true collective first: batched point-to-point calls may involve a subset of
+    # the ranks only AFTER the group's first collective (torch.distributed docs)
+    dist.barrier()
     # one untimed exchange in any case: RCCL builds its point-to-point channels
     # on first use (seconds), which must not land in a run started with --warmup 0
     exchange_ghosts(a, plan, dist)
