@@ -223,6 +223,21 @@ def annotate_cost(entry, spec):
   return entry
 
 
+def prefixed_options(options, prefix, emit):
+  """The `<prefix>name=value` entries of `options` as keyword arguments of `emit`;
+  a name `emit` does not take is an error, not a silently ignored knob."""
+  import inspect
+  known = inspect.signature(emit).parameters
+  out = {}
+  for key, value in options.items():
+    if key.startswith(prefix):
+      if key[len(prefix):] not in known:
+        raise TypeError('%s: %s() has no option `%s`' % (key, emit.__module__,
+                                                         key[len(prefix):]))
+      out[key[len(prefix):]] = value
+  return out
+
+
 def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
              fused=True, depths=None, inline=True, wave_groups=None,
              **fused_options):
@@ -384,8 +399,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
           # (kernel_stream3d_blk).  Named <app>_fused_k<d>b; with 'both' it ships
           # NEXT TO the wave-pipelined kernel and the run-time picks per launch
           options = dict(BLOCK_3D_OPTIONS)
-          options.update({k[4:]: v for k, v in fused_options.items()
-                          if k.startswith('blk_')})
+          options.update(prefixed_options(fused_options, 'blk_', kernel_stream3d_blk.emit))
           try:
             ftext, entry = kernel_stream3d_blk.emit(spec, depth, **options)
             parts.append(ftext)
@@ -394,11 +408,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
               continue
           except kernel_stream2d.NotFusable as e:
             notes.append('depth %d not in block form: %s' % (depth, e))
-        options = {k[3:]: v for k, v in fused_options.items()
-                   if k in ('wp_rows', 'wp_groups', 'wp_prefetch', 'wp_vgpr_budget', 'wp_split',
-                           'wp_lds_budget', 'wp_waves_per_eu', 'wp_loader', 'wp_sched_fence',
-                           'wp_ring_prefetch', 'wp_pairs', 'wp_xcd_remap', 'wp_prio',
-                           'wp_xcd_tiles', 'wp_buffer_io')}
+        options = prefixed_options(fused_options, 'wp_', kernel_stream3d_wp.emit)
         options.setdefault('groups', min(depth * len(spec['stages']), 4))
         if options.get('split', 2) == 2 and not options.get('loader') and \
             options.get('rows', 16) % 2 == 0 and kernel_stream2d_wp.packable(spec):
