@@ -14,6 +14,16 @@ from conftest import ROOT, SAMPLES
 
 SEED = 20240607
 BLOBS = os.path.join(ROOT, 'soda-compiler_amd', 'blobs')
+# The checker's shared objects of the GPU tests go to tests/_oracle_build (cached,
+# git-ignored), not oracle/_build: the driver records which in-tree .so files the
+# GPU test processes load, alphabetically and capped - dozens of oracle/_build/*.so
+# in front would push soda-compiler_amd/csrc/libsoda_hip.so (the product) off that list.
+ORACLE_BUILD = os.path.join(ROOT, 'tests', '_oracle_build')
+
+
+def make_oracle(spec, **kw):
+  from oracle import soda_oracle
+  return soda_oracle.Oracle(spec, build_dir=ORACLE_BUILD, **kw)
 
 
 def sample_path(app):

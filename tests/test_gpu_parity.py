@@ -43,7 +43,7 @@ def program(app):
 
 def oracle(app):
   if app not in _ORACLES:
-    _ORACLES[app] = soda_oracle.Oracle(gpu_util.load_spec(app))
+    _ORACLES[app] = gpu_util.make_oracle(gpu_util.load_spec(app))
   return _ORACLES[app]
 
 
@@ -175,7 +175,7 @@ def test_wave_pipelined_generator_forms(app, options):
   text, table = kernel.generate(spec, **options)
   assert any(k.get('groups') for k in table), [k['name'] for k in table]
   prog = host.open_program(source=text, spec=spec)
-  orc = soda_oracle.Oracle(spec)
+  orc = gpu_util.make_oracle(spec)
   try:
     for iterate, shape in ((8, (130, 1300)), (19, (300, 2100)), (9, (64, 64)),
                            (13, (90, 256)), (12, (70, 257)), (21, (50, 511)),
@@ -255,7 +255,7 @@ def test_3d_wave_pipelined_forms_on_heat3d(options):
     inputs = gpu_util.random_inputs(spec, shape)
     got, timing = prog.run_numpy(inputs, iterate=iterate, timed=True)
     assert timing['max_depth'] == 4
-    orc = soda_oracle.Oracle(spec)
+    orc = gpu_util.make_oracle(spec)
     want = orc.run(inputs, iterate=iterate)[spec['outputs'][0]]
     sl = orc.valid_slices(tuple(reversed(shape)), iterate)
     assert np.array_equal(got[0][sl], want[sl], equal_nan=True), (options, shape)
@@ -289,7 +289,7 @@ def test_3d_block_form(app, options):
     inputs = gpu_util.random_inputs(spec, shape)
     got, timing = prog.run_numpy(inputs, iterate=iterate, timed=True)
     assert timing['max_depth'] == 4
-    orc = soda_oracle.Oracle(spec)
+    orc = gpu_util.make_oracle(spec)
     want = orc.run(inputs, iterate=iterate)[spec['outputs'][0]]
     sl = orc.valid_slices(tuple(reversed(shape)), iterate)
     assert want[sl].size > 0
@@ -742,7 +742,7 @@ def test_one_dimensional_program_jit():
   prog = host.open_program(source=src, spec=spec)
   a = np.random.default_rng(3).random((100003,), dtype=np.float32)
   got = prog.run_numpy([a], iterate=3)[0]
-  orc = soda_oracle.Oracle(spec)
+  orc = gpu_util.make_oracle(spec)
   want = orc.run([a], iterate=3)['b']
   assert np.array_equal(got[3:-3], want[3:-3])
   assert got[3:-3].std() > 0
@@ -1135,7 +1135,7 @@ def test_run_on_data_in_the_reference_dram_layout(fixture):
                                        meta['banks_out'])
   c = layout.stencil_constants(st, meta['tile_size'])
   inputs = [data['in_' + n] for n in st.input_names]
-  orc = soda_oracle.Oracle(spec)
+  orc = gpu_util.make_oracle(spec)
   want = orc.run(inputs, iterate=meta['iterate'])
   sl = orc.valid_slices(tuple(meta['dims']), meta['iterate'])
   for name in st.output_names:

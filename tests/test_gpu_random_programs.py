@@ -7,7 +7,6 @@ integer programs over the remaining operators of the grammar (% & | ^ comparison
 && || unary - ~ !, non-decimal literals)."""
 import json
 import os
-import tempfile
 
 import numpy as np
 import pytest
@@ -16,7 +15,9 @@ from soda_hip import frontend
 from soda_hip.codegen import kernel
 from soda_hip.codegen import spec as specmod
 from soda_hip.runtime import host
-from oracle import soda_oracle
+from oracle import soda_oracle  # noqa: F401
+
+import gpu_util
 
 
 pytestmark = pytest.mark.gpu
@@ -27,7 +28,6 @@ with open(os.path.join(GOLDEN, 'random_programs.json')) as f:
   PROGRAMS = json.load(f)          # the texts the reference fixtures were made from
 with open(os.path.join(GOLDEN, 'random_manifest.json')) as f:
   REFERENCE = {v['key']: (k, v) for k, v in json.load(f).items() if k.endswith('.npz')}
-SCRATCH = tempfile.mkdtemp(prefix='soda_oracle_')      # not oracle/_build
 
 
 def run_case(key, shape, rng, **gen):
@@ -51,7 +51,7 @@ def run_case(key, shape, rng, **gen):
     ins = [np.ascontiguousarray(data['in_' + t['name']]) for t in spec['inputs']]
     cases.append((ins, {n: data['out_' + n] for n in spec['outputs']},
                   'reference fixture'))
-  orc = soda_oracle.Oracle(spec, build_dir=SCRATCH)
+  orc = gpu_util.make_oracle(spec)
   inputs = []
   for t in spec['inputs']:
     dt = np.dtype(specmod.NUMPY_NAME[t['c_type']])
