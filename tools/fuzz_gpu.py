@@ -2,7 +2,8 @@
 """Fuzzing run on the GPU box: fresh seeds of the random-program generators of the
 tests (tests/random_programs.py), HIP path (hiprtc) against the CPU oracle for every
 depth split.  Not a test: a hunt; a failing program goes into the committed families.
-usage: fuzz_gpu.py family first_seed count   (family: plain ops struct cube deep)"""
+usage: fuzz_gpu.py family first_seed count [generator options k=v,...]
+(family: plain ops struct cube deep)"""
 import os
 import sys
 import tempfile
@@ -44,7 +45,13 @@ for seed in range(first, first + count):
       lo, hi = boxes[name]
       for d in range(dim):
         shape[dim - 1 - d] = max(shape[dim - 1 - d], hi[d] - lo[d] + 20)
-    src, table = kernel.generate(spec)
+    gen_options = dict(kv.split('=') for kv in sys.argv[4].split(',')) \
+        if len(sys.argv) > 4 else {}
+    gen_options = {k: (int(v) if v.lstrip('-').isdigit() else v)
+                   for k, v in gen_options.items()}
+    if gen_options.get('blk_pairs') and ('int32' in text or 'local' in text):
+      gen_options = {k: v for k, v in gen_options.items() if k != 'blk_pairs'}
+    src, table = kernel.generate(spec, **gen_options)
     prog = host.open_program(source=src, spec=spec)
     orc = soda_oracle.Oracle(spec, build_dir=scratch)
     inputs = []
