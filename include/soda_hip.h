@@ -169,7 +169,12 @@ typedef struct soda_hip_kernel {
                          (dimensions 0 and 1) into super-tiles of SX x SY tiles,
                          passes param[1] = SX | SY << 16 and param[2] = (super-
                          tiles along x) | (along y) << 16, and launches
-                         ceil(super-tiles x chunks / 8) x 8 x SX x SY workgroups */
+                         ceil(super-tiles x chunks / 8) x 8 x SX x SY workgroups.
+                         N < 0: a 1-D grid of 8 P workgroups, P = ceil(tiles / 8) in
+                         param[3]; workgroup L works on tile (L mod 8) P + L / 8
+                         of the x-fastest tile order (XCD L mod 8 takes a RUN of
+                         consecutive tiles); param[1] = 1 | 1 << 16, param[2] =
+                         (tiles along x) | (along y) << 16 */
 } soda_hip_kernel;
 
 /* By-value argument of every generated kernel. */
@@ -180,7 +185,7 @@ typedef struct soda_hip_args {
   int64_t box_hi[SODA_HIP_MAX_DIMS];
   int64_t param[4]; /* param[0]: outer-dimension rows per workgroup, chosen per
                        launch so that the grid fills the chip in whole rounds;
-                       param[1], param[2]: see soda_hip_kernel.xcd_tiles */
+                       param[1], param[2], param[3]: see soda_hip_kernel.xcd_tiles */
 } soda_hip_args;
 
 /* ---- plan -------------------------------------------------------------------

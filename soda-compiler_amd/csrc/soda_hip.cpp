@@ -318,7 +318,21 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
     out->grid[2] = (unsigned)gz;
     out->args.param[0] = 1;
   }
-  if (desc.xcd_tiles && dim == 3) {
+  if (desc.xcd_tiles < 0 && dim == 3) {
+    // Runs (kernel_stream3d_blk.py, xcd_runs): XCD x (= workgroup id mod 8) takes the
+    // tiles [x P, (x + 1) P) of the x-fastest order, P = ceil(tiles / 8), so that a
+    // tile's x- and y-neighbours stream beside it on the same L2.
+    const int64_t gx = out->grid[0], gy = out->grid[1], gz = out->grid[2];
+    const int64_t per = (gx * gy * gz + 7) / 8;
+    if (per * 8 > 2147483647LL || gx > 65535 || gy > 65535)
+      return fail(SODA_HIP_ERR_EXTENTS_TOO_LARGE, "grid of kernel %s would be %lld",
+                  desc.name, (long long)(per * 8));
+    out->args.param[1] = 1 | (1 << 16);
+    out->args.param[2] = gx | (gy << 16);
+    out->args.param[3] = per;
+    out->grid[0] = (unsigned)(per * 8);
+    out->grid[1] = out->grid[2] = 1;
+  } else if (desc.xcd_tiles && dim == 3) {
     // XCD-aware placement (kernel_stream3d_wp.py, xcd_tiles): the plane of
     // gx x gy tiles is cut into super-tiles of SX x SY tiles whose workgroups run
     // together on one XCD and share its L2.  Pick the shape that fetches least:
@@ -1057,6 +1071,21 @@ int soda_hip_sweep_timed(soda_hip_plan* plan, void* const* in, void* const* out,
         slot.second += 1;
       }
     }
+    if (tuning_env("SODA_HIP_LAUNCH_TRACE"))   // tools/: every launch, fastest repeat
+      for (size_t i = 0; i < list.size(); ++i) {
+        float fastest = 0;
+        for (int r = 0; r < repeats; ++r) {
+          float k_ms = 0;
+          (void)hipEventElapsedTime(&k_ms, ev[r * per + i], ev[r * per + i + 1]);
+          if (r == 0 || k_ms < fastest) fastest = k_ms;
+        }
+        const soda_hip_args& a = list[i].args;
+        fprintf(stderr, "soda_hip: launch %3zu %-28s %8.1f us (model %7.1f)  box %lld x %lld x %lld  "
+                "grid %u x %u x %u  chunk %lld\n", i, plan->kernels[list[i].kernel].name,
+                fastest * 1000.0, list[i].est_us, (long long)(a.box_hi[0] - a.box_lo[0]),
+                (long long)(a.box_hi[1] - a.box_lo[1]), (long long)(a.box_hi[2] - a.box_lo[2]),
+                list[i].grid[0], list[i].grid[1], list[i].grid[2], (long long)a.param[0]);
+      }
     timing->kernel_us = total_ms * 1000.0 / repeats;
     timing->launches = (int)list.size();
     timing->max_depth = depth;

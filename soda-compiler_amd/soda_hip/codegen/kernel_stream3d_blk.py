@@ -91,7 +91,8 @@ def build_chain(spec, depth, prefetch):
 
 def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
          max_period=12, vgpr_budget=250, waves_per_eu=0, xcd_tiles=1, ring=0,
-         pairs=0):
+         pairs=0, align_out=16, xcd_runs=1, stamps=0,
+         flat_stores=0):
   """Returns (text, kernel table entry).
 
   `prefetch` = input planes loaded ahead into REGISTERS (R*C VGPRs each);
@@ -110,7 +111,33 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   R/2-1 -> R/2 are a low half meeting its own high half): those operands, and the
   lane-crossing x-neighbours, are two scalars each (kernel_common: pk2_shifted,
   the DPP shift folded into a v_add_f32_dpp).  Same IEEE operations in the same
-  order as the scalar form."""
+  order as the scalar form.
+  `align_out` = N > 1: the tiles' output columns start on multiples of N cells and
+  are a multiple of N wide, so that the row segments two neighbouring workgroups
+  store meet on a 64-byte boundary (N = 16 floats) or a 128-byte line (N = 32).
+  tools/tile3dbench.hip (this kernel's access pattern without the arithmetic,
+  512^3): row segments that start 16 bytes into a line cost a pure copy +41 %
+  (a line shared by two workgroups leaves L2 as masked partial writes), 64 bytes
+  into it +14 %; with 120 of 128 columns kept (segments end anywhere) the copy
+  takes 294 us, with 112 kept 247 us, with 96 (whole lines, one more tile column)
+  266 us.  Misaligned LOADS cost 7 %.
+  `xcd_runs` = 1: each XCD (workgroup id mod 8) takes a RUN of consecutive tiles
+  (x fastest, then y, then z chunks) instead of every eighth one, so that tiles
+  which share halo cells and cache lines run on one L2: the copy 247 -> 236 us.
+  `flat_stores` = 1: the same R store instructions every step, a row or plane that is
+  not to be stored dropped by an out-of-range offset (what the ring form needs for its
+  counted wait).  Loads and stores share one in-order counter (vmcnt); behind stores
+  under branches the compiler must assume that none was issued, so its wait for the
+  prefetched plane (`vmcnt(8)`: only the loads just issued may be outstanding) also
+  waited for the acknowledgement of the stores issued a few hundred cycles earlier.
+  Measured (jacobi3d 512^3): 343 us against 294 us with the branches - the stamped
+  build shows the wavefronts stalled at the ISSUE of the stores (memory back-pressure),
+  and the select per row un-fuses the DPP adds; off.
+  `stamps` = device address of a debug buffer (tools/blk_stamps.py only): the
+  wavefront sums the shader cycles (s_memtime) it spends in each part of a step -
+  input plane, each stage instance, the barrier - and lane 0 writes the sums there;
+  scheduling fences keep the parts apart, so a stamped build is a diagnostic, not
+  the shipped kernel."""
   if spec['dim'] != 3:
     raise NotFusable('3-D programs only')
   types = specmod.tensor_c_types(spec)
@@ -142,6 +169,13 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   halo_lo = -(-lo[0] // C) * C
   halo_hi = -(-hi[0] // C) * C
   w_out = LANES * C - halo_lo - halo_hi
+  align_out = max(C, int(align_out))
+  if align_out % C:
+    raise NotFusable('align_out must be a multiple of the %d columns a lane holds' % C)
+  if w_out >= align_out:
+    w_out -= w_out % align_out
+  else:
+    align_out = C
   TR = G * R
   y_lo, y_hi = lo[1], hi[1]
   r_out = TR - y_lo - y_hi
@@ -315,6 +349,18 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     # the first planes are waited for outright; from step `ring` on the counted
     # wait below is exact
     line('  __builtin_amdgcn_s_waitcnt(%d);  // vmcnt(0)' % vmcnt(0))
+  if stamps:
+    line('  unsigned long long soda_t[%d];' % (len(insts) + 1))
+    for k in range(len(insts) + 1):
+      line('  soda_t[%d] = 0;' % k)
+    line('  unsigned long long soda_prev = __builtin_readcyclecounter();')
+
+  def stamp(k):
+    if stamps:
+      line('      __builtin_amdgcn_sched_barrier(0);')
+      line('      { const unsigned long long now = __builtin_readcyclecounter(); '
+           'soda_t[%d] += now - soda_prev; soda_prev = now; }' % k)
+      line('      __builtin_amdgcn_sched_barrier(0);')
   line('  for (i64 n = 0; n < steps; n += %d, head += %d) {' % (period, period))
 
   def out_cell(r, c):
@@ -366,7 +412,9 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
 
   for u in range(period):
     line('    {  // unrolled step %d' % u)
-    for inst in insts:
+    for inst_index, inst in enumerate(insts):
+      if inst_index:
+        stamp(inst_index - 1)
       if inst.stage is None and ring:
         s = slot(inst, u, 0)
         # plane head+u was issued `ring` steps ago; since then this wavefront has
@@ -439,7 +487,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
           cell_assignment(stage, target, load, line, '        ')
       if inst.up or inst.down:
         publish(inst, u, slot(inst, u, 0))
-      if inst.final and ring:
+      if inst.final and (ring or flat_stores):
         # the same number of stores every step (the counted wait above): a plane
         # or row that is not to be stored gets out-of-range offsets
         line('        const i64 z = head + %d;' % (u - L))
@@ -484,9 +532,19 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
           line('          }')
         line('        }')
       line('      }')
+    stamp(len(insts) - 1)
     line('    }')
     line('    %s();' % ('soda_lds_barrier' if ring else 'soda_block_barrier'))
+    stamp(len(insts))
   line('  }')
+  if stamps:
+    line('  if (lane == 0) {')
+    line('    unsigned long long* dbg = (unsigned long long*)%dull + '
+         '((i64)__builtin_amdgcn_workgroup_id_x() * %d + wave) * 16;' % (int(stamps), G))
+    for k in range(len(insts) + 1):
+      line('    dbg[%d] = soda_t[%d];' % (k, k))
+    line('    dbg[15] = (unsigned long long)steps;')
+    line('  }')
   line('}')
   line('')
   occupancy = ''
@@ -508,8 +566,10 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
          'SY = (unsigned)a.param[1] >> 16;')
     line('  const unsigned nsx = (unsigned)a.param[2] & 0xffffu, '
          'nsy = (unsigned)a.param[2] >> 16;')
-    line('  const unsigned S = SX * SY, i = L >> 3, g = (i / S) * 8u + (L & 7u), '
-         'within = i % S;')
+    # param[3] = P > 0: runs - XCD x = L mod 8 takes tiles [x P, (x + 1) P)
+    line('  const unsigned P = (unsigned)a.param[3];')
+    line('  const unsigned S = SX * SY, i = L >> 3, g = P ? (L & 7u) * P + i : '
+         '(i / S) * 8u + (L & 7u), within = P ? 0u : i % S;')
     line('  const unsigned block_x = (g % nsx) * SX + within % SX;')
     line('  const unsigned block_y = ((g / nsx) % nsy) * SY + within / SX;')
     line('  const unsigned block_z = g / (nsx * nsy);')
@@ -517,7 +577,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     line('  const unsigned block_x = __builtin_amdgcn_workgroup_id_x();')
     line('  const unsigned block_y = __builtin_amdgcn_workgroup_id_y();')
     line('  const unsigned block_z = __builtin_amdgcn_workgroup_id_z();')
-  line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % C)
+  line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % align_out)
   line('  const i64 xs = x_origin + (i64)block_x * %d;' % w_out)
   line('  if (xs >= a.box_hi[0]) return;')
   line('  const i64 yb = a.box_lo[1] + (i64)block_y * %d - %d;' % (r_out, y_lo))
@@ -538,9 +598,9 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('}')
   entry = dict(name=name, kind='fused', depth=depth, stage=-1,
                block=[G * LANES, 1, 1], tile=[w_out, r_out, chunk_planes, 1],
-               origin_align=C, fill_rows=L + lo[2], cols=C, rows=R, stack=G,
+               origin_align=align_out, fill_rows=L + lo[2], cols=C, rows=R, stack=G,
                prefetch=prefetch, period=period, est_vgprs=est_vgprs, w_out=w_out,
                r_out=r_out, lds_bytes=lds_bytes + ring_bytes, ring=ring, pairs=pairs,
-               xcd_tiles=int(bool(xcd_tiles)),
+               xcd_tiles=(-1 if xcd_runs else 1) if xcd_tiles else 0,
                min_extent=[LANES * C, TR])
   return '\n'.join(o) + '\n', entry

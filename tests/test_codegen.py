@@ -183,9 +183,15 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   text, table = kernel.generate(spec)
   blk = [k for k in table if k['kind'] == 'fused' and k['depth'] == 4 and k.get('stack')]
   assert [k['name'] for k in blk] == ['jacobi3d_fused_k4b']
-  assert blk[0]['block'] == [512, 1, 1] and blk[0]['tile'][:2] == [120, 56]
+  # 112 of the 120 columns a tile could keep: row segments of neighbouring tiles
+  # meet on 64-byte boundaries (origin_align 16 floats); XCD runs (xcd_tiles -1)
+  assert blk[0]['block'] == [512, 1, 1] and blk[0]['tile'][:2] == [112, 56]
+  assert blk[0]['origin_align'] == 16
   assert blk[0]['min_extent'] == [128, 64] and blk[0]['prefetch'] == 1
-  assert blk[0]['xcd_tiles'] == 1 and blk[0]['fill_rows'] == 9
+  assert blk[0]['xcd_tiles'] == -1 and blk[0]['fill_rows'] == 9
+  loose = [k for k in kernel.generate(spec, blk_align_out=2, blk_xcd_runs=0)[1]
+           if k.get('stack')]
+  assert loose[0]['tile'][:2] == [120, 56] and loose[0]['xcd_tiles'] == 1
   assert 'edges[' in text and 'soda_block_barrier' in text
   k4 = [k for k in table if k['kind'] == 'fused' and k['depth'] == 4 and k.get('groups')]
   assert k4 and k4[0]['groups'] == 4 and k4[0]['block'] == [256, 1, 1]

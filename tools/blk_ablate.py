@@ -12,7 +12,9 @@ from soda_hip.runtime import host
 
 app, n = sys.argv[1], int(sys.argv[2])
 opts = {k: (int(v) if v.lstrip('-').isdigit() else v)
-        for k, v in (kv.split('=') for kv in sys.argv[3].split(',') if kv)}
+        for k, v in (kv.split('=', 1) for kv in sys.argv[3].split(',') if kv)}
+# flags=-mllvm:-amdgpu-sched-strategy=max-ilp -> extra hipcc flags
+flags = opts.pop('flags', '').split(':') if opts.get('flags') else []
 st = frontend.load(os.path.join(ROOT, 'tests', 'samples', app + '.soda'), iterate=4)
 spec = specmod.spec_from_stencil(st)
 text, table = kernel.generate(spec, **opts)
@@ -42,7 +44,7 @@ for name, fn in variants:
   src = fn(text)
   assert name == 'baseline' or src != text, name
   path = '/tmp/ablate_%d.hsaco' % os.getpid()
-  kernel.compile_to_code_object(src, path)
+  kernel.compile_to_code_object(src, path, extra_flags=flags)
   prog = host.open_program(blob=path, spec=spec)
   t = prog.sweep_timed([din.ptr], [dout.ptr], [n, n, n], 4, warmup=3, repeats=5)
   print('%-28s %8.1f us  [%s]' % (name, t['kernel_us'], t['dominant_name']), flush=True)

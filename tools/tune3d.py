@@ -27,12 +27,14 @@ orc = soda_oracle.Oracle(spec)
 for variant in sys.argv[4:] or ['']:
   opts = {k: ([int(x) for x in v.split('/')] if '/' in v else
               int(v) if v.lstrip('-').isdigit() else v)
-          for k, v in (kv.split('=') for kv in variant.split(',') if kv)}
+          for k, v in (kv.split('=', 1) for kv in variant.split(',') if kv)}
+  # flags=-mllvm:-amdgpu-sched-strategy=max-ilp  -> extra hipcc flags (TUNE_HIPCC=1)
+  flags = opts.pop('flags', '').split(':') if opts.get('flags') else []
   text, table = kernel.generate(spec, **opts)
   try:
     if os.environ.get('TUNE_HIPCC'):     # offline compile, as the shipped blobs
       path = '/tmp/tune3d_%d.hsaco' % os.getpid()
-      kernel.compile_to_code_object(text, path)
+      kernel.compile_to_code_object(text, path, extra_flags=flags)
       prog = host.open_program(blob=path, spec=spec)
     else:
       prog = host.open_program(source=text, spec=spec)
