@@ -261,6 +261,16 @@ int soda_hip_plan_schedule(soda_hip_plan* plan,
  * tuning. */
 int soda_hip_plan_set_max_depth(soda_hip_plan* plan, int max_depth);
 
+/* on != 0: a sweep writes `out` with its LAST launch only; the launches before it
+ * alternate between two plan-owned arrays (the second one is allocated when a sweep
+ * first needs it).  By default the intermediate launches alternate between one
+ * plan-owned array and `out`, i.e. `out` also receives the larger boxes of earlier
+ * levels.  A caller that sweeps SUB-ARRAYS of one output array piece by piece (the
+ * overlapped multi-GPU schedule: boundary bands first, interior later,
+ * soda_hip/runtime/dist.py) needs this: an intermediate box of one piece would
+ * reach into rows another piece has already finished. */
+int soda_hip_plan_set_out_final_only(soda_hip_plan* plan, int on);
+
 /* ---- multi-GPU: one slab of a larger grid ------------------------------------
  * The reference has nothing distributed (one FPGA); what must be preserved is its
  * semantics: no boundary condition, the valid box shrinks every iteration
@@ -285,6 +295,16 @@ typedef struct soda_hip_slab {
   int64_t dims[SODA_HIP_MAX_DIMS]; /* the GLOBAL grid */
   int64_t own_first, own_last;     /* this rank's rows of the outermost dimension */
 } soda_hip_slab;
+
+/* The exchange period every rank of an even cut uses (soda_hip/runtime/dist.py:
+ * SlabPlan applies the same rule): a ghost region cannot be deeper than the smallest
+ * slab, floor(rows / world) rows, so
+ *   *exchange = world > 1 ? max(1, min(wanted, floor(rows / world) / reach)) : wanted,
+ * reach = max(reach_lo, reach_hi, 1).  SODA_HIP_ERR_CONSTRAINT when the smallest slab
+ * is thinner than the reach of ONE iteration (no exchange period can work).  Every
+ * rank computes this from global figures, so all agree before the first message. */
+int soda_hip_slab_exchange(int64_t rows, int world, int reach_lo, int reach_hi,
+                           int wanted, int* exchange);
 
 /* extents of the rank's local arrays (own rows + ghost rows) and the ghost depths */
 int soda_hip_slab_extent(const soda_hip_plan* plan, const soda_hip_slab* slab,

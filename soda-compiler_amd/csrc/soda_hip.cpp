@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -84,6 +85,11 @@ struct soda_hip_plan {
   // reach every CU (jacobi3d 128^3, depth 4: 67 us per launch with 32-plane
   // chunks)
   int chunk_rows_min = 8;
+  // soda_hip_plan_set_out_final_only: `out` is written by the LAST launch of a sweep
+  // only; the launches before it alternate between scratch and scratch_b
+  bool out_final_only = false;
+  std::vector<void*> scratch_b;      // second partner per output (out_final_only)
+  std::vector<size_t> scratch_b_bytes;
   // scratch: [0, n_outputs) ping-pong partner of the outputs,
   // then one per non-output stage (only used by per-stage kernels)
   std::vector<void*> scratch;
@@ -91,6 +97,9 @@ struct soda_hip_plan {
   // composed boxes per iteration per stage, grown on demand
   std::vector<std::vector<Box>> boxes;
   std::vector<Box> feed;
+  // XCD super-tile shape chosen per (kernel, tiles along x, y, chunks): the search
+  // walks every super-tile and a sweep's launches mostly repeat a few grids
+  mutable std::map<std::array<int64_t, 4>, std::pair<int, int>> xcd_shape;
 };
 
 namespace {
@@ -160,7 +169,7 @@ void output_margins(soda_hip_plan* plan, int iterations, int32_t* lo, int32_t* h
 }
 
 int ensure_scratch(soda_hip_plan* plan, const int64_t* dims, bool need_locals,
-                   bool need_pingpong, hipStream_t stream) {
+                   bool need_pingpong, hipStream_t stream, bool need_second = false) {
   const soda_hip_program& p = plan->prog;
   size_t cells = 1;
   for (int d = 0; d < p.dim; ++d) cells *= (size_t)dims[d];
@@ -190,6 +199,24 @@ int ensure_scratch(soda_hip_plan* plan, const int64_t* dims, bool need_locals,
       int rc = want(j, cells * p.elem_size[p.output_tensor[j]]);
       if (rc) return rc;
     }
+  if (need_second) {
+    if ((int)plan->scratch_b.size() != p.n_outputs) {
+      plan->scratch_b.assign(p.n_outputs, nullptr);
+      plan->scratch_b_bytes.assign(p.n_outputs, 0);
+    }
+    for (int j = 0; j < p.n_outputs; ++j) {
+      const size_t bytes = cells * p.elem_size[p.output_tensor[j]];
+      if (plan->scratch_b_bytes[j] >= bytes) continue;
+      if (plan->scratch_b[j]) {
+        HIP_TRY(SODA_HIP_ERR_DEVICE_FREE, hipFree(plan->scratch_b[j]));
+        plan->scratch_b[j] = nullptr;
+        plan->scratch_b_bytes[j] = 0;
+      }
+      HIP_TRY(SODA_HIP_ERR_DEVICE_MALLOC, hipMalloc(&plan->scratch_b[j], bytes));
+      HIP_TRY(SODA_HIP_ERR_DEVICE_RUN, hipMemsetAsync(plan->scratch_b[j], 0, bytes, stream));
+      plan->scratch_b_bytes[j] = bytes;
+    }
+  }
   if (need_locals)
     for (int s = 0; s < p.n_stages; ++s) {
       const int t = p.n_inputs + s;
@@ -370,7 +397,11 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
     // written bytes) but every one measured ran SLOWER (cfg5 6.2 -> 7.0-7.4 ms)
     int max_group = std::max(1, (int)desc.xcd_tiles);   // the kernel's own limit
     if (const char* env = tuning_env("SODA_HIP_XCD_GROUP")) max_group = std::max(1, atoi(env));
-    for (int sx = 1; sx <= 8; ++sx)
+    const std::array<int64_t, 4> key = {k, gx, gy, gz};
+    const auto known = plan->xcd_shape.find(key);
+    const bool cached = known != plan->xcd_shape.end() && !tuning_env("SODA_HIP_XCD_GROUP");
+    if (cached) { best_sx = known->second.first; best_sy = known->second.second; }
+    for (int sx = 1; sx <= 8 && !cached; ++sx)
       for (int sy = 1; sy <= 8; ++sy) {
         if (sx * sy > max_group) continue;
         const int64_t nsx = (gx + sx - 1) / sx, nsy = (gy + sy - 1) / sy;
@@ -388,6 +419,8 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
                             (1 + 0.25 * hy / (std::min<int64_t>(sy, gy) * r));
         if (best < 0 || cost < best) { best = cost; best_sx = sx; best_sy = sy; }
       }
+    if (!cached && !tuning_env("SODA_HIP_XCD_GROUP"))
+      plan->xcd_shape[key] = std::make_pair(best_sx, best_sy);
     if (const char* env = tuning_env("SODA_HIP_XCD_TILES")) {   // tuning: "SX,SY"
       int sx = 0, sy = 0;
       if (sscanf(env, "%d,%d", &sx, &sy) == 2 && sx > 0 && sy > 0) { best_sx = sx; best_sy = sy; }
@@ -475,7 +508,9 @@ int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
     // 3-D ones index inside a plane with 32 bits (2-D ones are 64-bit throughout)
     if (kd.min_extent[0] > 0 &&
         (dims[0] < kd.min_extent[0] || (p.dim > 1 && dims[1] < kd.min_extent[1]) ||
-         (p.dim > 2 && dims[0] * dims[1] >= (int64_t(1) << 30))))
+         // (a lane that must not store gets byte offset 0xfffffff0 in the plane's
+         // buffer resource: the plane must end below that, widest store included)
+         (p.dim > 2 && dims[0] * dims[1] >= (int64_t(1) << 30) - 16)))
       continue;
     fused.push_back((int)k);
   }
@@ -557,22 +592,27 @@ int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
         fprintf(stderr, " k%d %.1f us", plan->kernels[usable[i]].depth, price[i]);
       fprintf(stderr, ")\n");
     }
+    // out_final_only: the m - 1 launches before the last alternate between the two
+    // plan-owned arrays (two of them need the second one)
+    const bool second = plan->out_final_only && m > 2;
     if (m > 1 && !dry) {
-      int rc = ensure_scratch(plan, dims, false, true, stream);
+      int rc = ensure_scratch(plan, dims, false, true, stream, second);
       if (rc) return rc;
     }
     int done = 0;
     std::vector<void*> src(in, in + p.n_inputs);
     for (int i = 0; i < m; ++i) {
       const soda_hip_kernel& desc = plan->kernels[seq[i]];
-      // destinations alternate so that the last one is `out`
-      const bool to_out = ((m - 1 - i) % 2) == 0;
+      // destinations alternate so that the last one is `out` (out_final_only: the
+      // others alternate between the plan's two arrays and never touch `out`)
+      const bool to_out = plan->out_final_only ? i == m - 1 : ((m - 1 - i) % 2) == 0;
+      const bool to_b = plan->out_final_only && second && ((m - 1 - i) % 2) == 0;
       soda_hip_args a;
       memset(&a, 0, sizeof a);
       for (int j = 0; j < p.n_inputs; ++j) a.tensor[j] = src[j];
       std::vector<void*> dst(p.n_outputs);
       for (int j = 0; j < p.n_outputs; ++j) {
-        dst[j] = to_out ? out[j] : plan->scratch[j];
+        dst[j] = to_out ? out[j] : to_b && !dry ? plan->scratch_b[j] : plan->scratch[j];
         a.tensor[p.output_tensor[j]] = dst[j];
       }
       int32_t mlo[SODA_HIP_MAX_DIMS], mhi[SODA_HIP_MAX_DIMS];
@@ -623,13 +663,16 @@ int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
   for (int s = 0; s < p.n_stages; ++s)
     if (stage_kernel[s] < 0)
       return fail(SODA_HIP_ERR_NO_KERNEL, "blob has no kernel for stage %d", s);
+  const bool second_st = plan->out_final_only && iterate > 2;
   if (!dry) {
-    int rc = ensure_scratch(plan, dims, true, iterate > 1, stream);
+    int rc = ensure_scratch(plan, dims, true, iterate > 1, stream, second_st);
     if (rc) return rc;
   }
   std::vector<void*> src(in, in + p.n_inputs);
   for (int it = 0; it < iterate; ++it) {
-    const bool to_out = ((iterate - 1 - it) % 2) == 0;
+    const bool to_out = plan->out_final_only ? it == iterate - 1
+                                             : ((iterate - 1 - it) % 2) == 0;
+    const bool to_b = second_st && !dry && ((iterate - 1 - it) % 2) == 0;
     soda_hip_args a;
     memset(&a, 0, sizeof a);
     for (int j = 0; j < p.n_inputs; ++j) a.tensor[j] = src[j];
@@ -637,7 +680,7 @@ int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
     for (int s = 0; s < p.n_stages; ++s)
       a.tensor[p.n_inputs + s] = plan->scratch[p.n_outputs + s];
     for (int j = 0; j < p.n_outputs; ++j) {
-      dst[j] = to_out ? out[j] : plan->scratch[j];
+      dst[j] = to_out ? out[j] : to_b ? plan->scratch_b[j] : plan->scratch[j];
       a.tensor[p.output_tensor[j]] = dst[j];
     }
     for (int d = 0; d < SODA_HIP_MAX_DIMS; ++d) a.dims[d] = d < p.dim ? dims[d] : 1;
@@ -968,6 +1011,9 @@ int soda_hip_plan_destroy(soda_hip_plan* plan) {
   for (void* ptr : plan->scratch)
     if (ptr && hipFree(ptr) != hipSuccess)
       rc = fail(SODA_HIP_ERR_DEVICE_FREE, "hipFree of plan scratch failed");
+  for (void* ptr : plan->scratch_b)
+    if (ptr && hipFree(ptr) != hipSuccess)
+      rc = fail(SODA_HIP_ERR_DEVICE_FREE, "hipFree of plan scratch failed");
   delete plan;
   return rc;
 }
@@ -983,6 +1029,12 @@ int soda_hip_plan_margins(const soda_hip_plan* plan, int iterations,
 int soda_hip_plan_set_max_depth(soda_hip_plan* plan, int max_depth) {
   if (!plan) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "plan is NULL");
   plan->max_depth = max_depth;
+  return 0;
+}
+
+int soda_hip_plan_set_out_final_only(soda_hip_plan* plan, int on) {
+  if (!plan) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "plan is NULL");
+  plan->out_final_only = on != 0;
   return 0;
 }
 
@@ -1165,6 +1217,23 @@ int slab_geometry(const soda_hip_plan* plan, const soda_hip_slab* s, SlabGeometr
 }
 
 }  // namespace
+
+int soda_hip_slab_exchange(int64_t rows, int world, int reach_lo, int reach_hi,
+                           int wanted, int* exchange) {
+  if (!exchange) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  if (rows < 1 || world < 1 || wanted < 1 || reach_lo < 0 || reach_hi < 0)
+    return fail(SODA_HIP_ERR_CONSTRAINT, "slab figures out of range");
+  const int64_t reach = std::max(1, std::max(reach_lo, reach_hi));
+  const int64_t smallest = rows / world;
+  if (world > 1 && smallest < reach)
+    return fail(SODA_HIP_ERR_CONSTRAINT,
+                "cannot cut %lld rows into %d slabs: the smallest slab (%lld rows) is "
+                "thinner than the stencil reach (%lld)", (long long)rows, world,
+                (long long)smallest, (long long)reach);
+  *exchange = world > 1 ? (int)std::max<int64_t>(1, std::min<int64_t>(wanted, smallest / reach))
+                        : wanted;
+  return 0;
+}
 
 int soda_hip_slab_extent(const soda_hip_plan* plan, const soda_hip_slab* slab,
                          int64_t local_dims[SODA_HIP_MAX_DIMS], int64_t* ghost_lo,

@@ -70,8 +70,31 @@ def _open(path):
   return open(path, 'w'), True
 
 
+IGNORED_OVERRIDES = (('unroll_factor', '--unroll-factor'), ('tile_size', '--tile-size'),
+                     ('dram_in', '--dram-in'), ('dram_out', '--dram-out'))
+
+
+def warn_ignored_overrides(args):
+  """The reference's FPGA knobs are accepted (same command lines keep working) and
+  carried in the kernel metadata, but no HIP generator reads them: they change how
+  the FPGA computes, never what (the reference's CPU loops, host.py:1076-1117, do
+  not mention them; unroll factor = PEs per stage, hls_kernel.py:157-160; tile size
+  = line-buffer length, core.py:612-635).  Here the cells per lane follow from
+  `burst width` (--hip-cols) and tiles / chunks are chosen per launch by the
+  run-time.  Said once, at warning level, when a flag is given explicitly."""
+  given = [flag for attr, flag in IGNORED_OVERRIDES
+           if getattr(args, attr, None) is not None]
+  if given:
+    _logger.warning(
+        'the HIP back end ignores %s: FPGA micro-architecture knobs (results never '
+        'depend on them); use --hip-cols / --hip-max-depth / --hip-chunk-rows to '
+        'steer the GPU kernels', ', '.join(given))
+  return given
+
+
 def print_code(stencil, args):
   spec = to_spec(stencil)
+  warn_ignored_overrides(args)
   max_depth = getattr(args, 'hip_max_depth', None)
   files = dict(kernel=getattr(args, 'hip_kernel_file', None),
                host=getattr(args, 'hip_host_file', None),

@@ -169,7 +169,7 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
   (ncclCommInitAll + soda_hip_run_slab).  Compiled in with -DSODA_HIP_MULTI_GPU
   (needs -lrccl -lpthread).  Same protocol as `<app>`: caller owns the host
   arrays, only the valid interior of the output is written."""
-  w('#ifdef SODA_HIP_MULTI_GPU\n#include <rccl/rccl.h>\n#include <thread>\n'
+  w('#ifdef SODA_HIP_MULTI_GPU\n#include <rccl/rccl.h>\n#include <thread>\n#include <mutex>\n#include <condition_variable>\n'
     '#include <vector>\n')
   w('extern "C" int %s_multi_gpu(buffer_t* var_%s_buffer, buffer_t* var_%s_buffer, '
     'const char* blob, int iterate, int ngpu) {\n' % (app, name_in, name_out))
@@ -188,18 +188,38 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
     '      fprintf(*error_report, "ERROR: ncclCommInitAll failed\\n");\n'
     '      return SODA_HIP_ERR_NO_DEVICE;\n    }\n  }\n')
   w('  std::vector<int> status(ngpu, 0);\n')
+  # Every rank derives the SAME exchange period from global figures before anything is
+  # sent (soda_hip_slab_exchange = the rule of runtime/dist.py: SlabPlan); a rank that
+  # fails during set-up is seen by all at a rendezvous in front of the first message,
+  # and one that fails later aborts every communicator so that no peer stays blocked
+  # in ncclRecv.
+  w('  std::mutex gate; std::condition_variable gate_cv; int arrived = 0; '
+    'bool setup_failed = false, aborted = false;\n')
+  w('  auto rendezvous = [&](bool ok) {\n'
+    '    std::unique_lock<std::mutex> lock(gate);\n'
+    '    if (!ok) setup_failed = true;\n'
+    '    if (++arrived == ngpu) gate_cv.notify_all();\n'
+    '    else gate_cv.wait(lock, [&] { return arrived == ngpu; });\n'
+    '    return !setup_failed;\n  };\n')
+  w('  auto abort_all = [&]() {\n'
+    '    std::lock_guard<std::mutex> lock(gate);\n'
+    '    if (aborted) return;\n    aborted = true;\n'
+    '    for (ncclComm_t& comm : comms) if (comm) { ncclCommAbort(comm); comm = nullptr; }\n'
+    '  };\n')
   w('  auto worker = [&](int rank) {\n')
   w('    int& rc = status[rank];\n')
   w('    soda_hip_module* module = nullptr;\n    soda_hip_plan* plan = nullptr;\n')
   w('    void *a = nullptr, *b = nullptr, *c = nullptr, *result = nullptr;\n')
-  w('    if ((rc = soda_hip_set_device(rank))) return;\n')
-  w('    if ((rc = soda_hip_module_load_file(blob, &module))) return;\n')
+  w('    soda_hip_slab slab;\n    memset(&slab, 0, sizeof slab);\n')
+  w('    int64_t local[4] = {1, 1, 1, 1}, ghost_lo = 0, ghost_hi = 0, own = 0;\n')
+  w('    size_t row_bytes = 0;\n')
+  w('    rc = soda_hip_set_device(rank);\n')
+  w('    if (!rc) rc = soda_hip_module_load_file(blob, &module);\n')
   w('    soda_hip_program program;\n    fill_program(&program);\n')
   w('    soda_hip_kernel kernels[32];\n    const int n_kernels = fill_kernels(kernels);\n')
-  w('    rc = soda_hip_plan_create(module, &program, kernels, n_kernels, &plan);\n')
+  w('    if (!rc) rc = soda_hip_plan_create(module, &program, kernels, n_kernels, &plan);\n')
   w('    if (rc == 0) {\n')
   w('      int32_t lo[4], hi[4];\n      soda_hip_plan_margins(plan, 1, lo, hi);\n')
-  w('      soda_hip_slab slab;\n      memset(&slab, 0, sizeof slab);\n')
   w('      slab.rank = rank; slab.world = ngpu;\n')
   w('      slab.reach_lo = lo[last]; slab.reach_hi = hi[last];\n')
   w('      for (int d = 0; d < dim; ++d) slab.dims[d] = in->extent[d];\n')
@@ -214,13 +234,14 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
     'base * 15) exchange -= %d;\n' % (deepest, deepest))
   w('      if (exchange > iterate) exchange = iterate;\n')
   w('      if (exchange < 1) exchange = 1;\n')
+  w('      // never deeper than the smallest slab (all ranks compute the same value)\n')
+  w('      rc = soda_hip_slab_exchange(rows, ngpu, lo[last], hi[last], exchange, &exchange);\n')
   w('      slab.exchange = ngpu > 1 ? exchange : iterate;\n')
-  w('      int64_t local[4], ghost_lo = 0, ghost_hi = 0;\n')
-  w('      rc = soda_hip_slab_extent(plan, &slab, local, &ghost_lo, &ghost_hi);\n')
-  w('      size_t row_bytes = (size_t)in->elem_size;\n')
+  w('      if (!rc) rc = soda_hip_slab_extent(plan, &slab, local, &ghost_lo, &ghost_hi);\n')
+  w('      row_bytes = (size_t)in->elem_size;\n')
   w('      for (int d = 0; d < last; ++d) row_bytes *= (size_t)in->extent[d];\n')
   w('      const size_t bytes = row_bytes * (size_t)local[last];\n')
-  w('      const int64_t own = slab.own_last - slab.own_first;\n')
+  w('      own = slab.own_last - slab.own_first;\n')
   w('      if (!rc) rc = soda_hip_malloc(&a, bytes);\n')
   w('      if (!rc) rc = soda_hip_malloc(&b, bytes);\n')
   w('      if (!rc) rc = soda_hip_malloc(&c, bytes);\n')
@@ -230,9 +251,21 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
   w('      if (!rc) rc = soda_hip_memcpy_h2d((char*)a + ghost_lo * row_bytes, '
     'in->host + slab.own_first * row_bytes, own * row_bytes, nullptr);\n')
   w('      if (!rc) rc = soda_hip_stream_synchronize(nullptr);\n')
-  w('      if (!rc) rc = soda_hip_run_slab(plan, &slab, comms[rank], a, b, c, iterate, '
+  w('    }\n')
+  w('    if (rc) fprintf(*error_report, "ERROR: GPU %d: %s: %s\\n", rank, '
+    'soda_hip_error_name(rc), soda_hip_last_error());\n')
+  w('    // nobody sends before everybody is ready to receive\n')
+  w('    const bool go = rendezvous(rc == 0);\n')
+  w('    if (!go && !rc) rc = SODA_HIP_ERR_GENERIC;   // a peer failed during set-up\n')
+  w('    if (go) {\n')
+  w('      rc = soda_hip_run_slab(plan, &slab, comms[rank], a, b, c, iterate, '
     'nullptr, &result, nullptr);\n')
   w('      if (!rc) rc = soda_hip_stream_synchronize(nullptr);\n')
+  w('      if (rc) {\n')
+  w('        fprintf(*error_report, "ERROR: GPU %d: %s: %s\\n", rank, '
+    'soda_hip_error_name(rc), soda_hip_last_error());\n')
+  w('        if (ngpu > 1) abort_all();   // peers blocked in ncclRecv return with an error\n')
+  w('      }\n')
   w('      if (!rc) {\n')
   w('        // only the valid interior goes back to the caller (host.py:838-899)\n')
   w('        std::vector<uint8_t> stage(own * row_bytes);\n')
@@ -257,8 +290,6 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
   w('            memcpy(out->host + y * row_bytes + off, stage.data() + '
     '(y - slab.own_first) * row_bytes + off, (size_t)(x1 - x0) * es);\n')
   w('          }\n        }\n      }\n    }\n')
-  w('    if (rc) fprintf(*error_report, "ERROR: GPU %d: %s: %s\\n", rank, '
-    'soda_hip_error_name(rc), soda_hip_last_error());\n')
   w('    soda_hip_free(a); soda_hip_free(b); soda_hip_free(c);\n')
   w('    soda_hip_plan_destroy(plan);\n    soda_hip_module_unload(module);\n')
   w('  };\n')

@@ -114,11 +114,15 @@ SIGNATURES = {
                                               ctypes.c_int,
                                               ctypes.POINTER(ctypes.c_int)]),
     'soda_hip_plan_set_max_depth': (ctypes.c_int, [_VP, ctypes.c_int]),
+    'soda_hip_plan_set_out_final_only': (ctypes.c_int, [_VP, ctypes.c_int]),
     'soda_hip_sweep': (ctypes.c_int, [_VP, _VPP, _VPP, _I64P, ctypes.c_int, _I32P,
                                       _I32P, _VP]),
     'soda_hip_sweep_timed': (ctypes.c_int, [_VP, _VPP, _VPP, _I64P, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, _VP,
                                             ctypes.POINTER(Timing)]),
+    'soda_hip_slab_exchange': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int,
+                                              ctypes.POINTER(ctypes.c_int)]),
     'soda_hip_slab_extent': (ctypes.c_int, [_VP, ctypes.POINTER(Slab), _I64P, _I64P,
                                             _I64P]),
     'soda_hip_run_slab': (ctypes.c_int, [_VP, ctypes.POINTER(Slab), _VP, _VP, _VP, _VP,

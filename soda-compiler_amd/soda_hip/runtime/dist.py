@@ -195,7 +195,11 @@ def run_slab(engine, plan, arrays, iterate, margins_of, dist, ghosts_ready=False
           plo[-1] = 0
         if cut_hi:
           phi[-1] = 0
-        engine.sweep(src, dst, plan.local_dims, step, plo, phi, rows=(r0, r1))
+        # final_only: a piece's sub-array of dst overlaps rows another piece has
+        # finished (and that are being sent): only the piece's LAST launch, whose
+        # box is exactly its own rows, may write dst
+        engine.sweep(src, dst, plan.local_dims, step, plo, phi, rows=(r0, r1),
+                     final_only=True)
       for band in bands:
         piece(*band)
       schedule.after_bands()
@@ -237,10 +241,17 @@ class HipEngine:
 
   def __init__(self, program, torch):
     self.program, self.torch = program, torch
+    self.final_only = False
 
-  def sweep(self, src, dst, local_dims, iterations, valid_lo, valid_hi, rows=None):
+  def sweep(self, src, dst, local_dims, iterations, valid_lo, valid_hi, rows=None,
+            final_only=False):
     """rows = (r0, r1): sweep only the sub-array of those rows of the outermost
-    dimension (a contiguous piece of memory: the same call on offset pointers)."""
+    dimension (a contiguous piece of memory: the same call on offset pointers).
+    final_only: dst is written by the sweep's last launch only
+    (soda_hip_plan_set_out_final_only)."""
+    if final_only != self.final_only:
+      self.program.set_out_final_only(final_only)
+      self.final_only = final_only
     stream = self.torch.cuda.current_stream().cuda_stream
     dims = list(local_dims)
     sp, dp = src.data_ptr(), dst.data_ptr()
@@ -279,8 +290,11 @@ class StreamSchedule:
 
   def exchange(self, fn):
     main = self.torch.cuda.current_stream()
-    if self.ghosts_landed is None and not self.spans:
-      self.side.wait_stream(main)       # the first exchange follows the input
+    # the rows to be sent were produced on the main stream (the input, the band
+    # sweeps, or - small slabs - a whole-slab sweep): the side stream follows
+    # everything enqueued there so far.  (after_bands() alone covered only the
+    # banded super-steps.)
+    self.side.wait_stream(main)
     t0 = self.torch.cuda.Event(enable_timing=True)
     t1 = self.torch.cuda.Event(enable_timing=True)
     with self.torch.cuda.stream(self.side):

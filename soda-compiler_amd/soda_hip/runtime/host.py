@@ -232,6 +232,11 @@ class Program:
     """0 = deepest fused kernels available, -1 = per-stage kernels only."""
     capi.check(capi.lib().soda_hip_plan_set_max_depth(self.handle, depth))
 
+  def set_out_final_only(self, on):
+    """Sweeps write their output arrays with the last launch only (callers that
+    sweep one array piece by piece: soda_hip_plan_set_out_final_only)."""
+    capi.check(capi.lib().soda_hip_plan_set_out_final_only(self.handle, int(bool(on))))
+
   def margins(self, iterations):
     lo = (ctypes.c_int32 * 4)()
     hi = (ctypes.c_int32 * 4)()

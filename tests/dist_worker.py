@@ -22,11 +22,17 @@ from oracle import soda_oracle                     # noqa: E402
 class OracleEngine:
   """sweep() with the same contract as libsoda_hip's soda_hip_sweep."""
 
-  def __init__(self, spec):
+  def __init__(self, spec, launch_depth=0):
+    """launch_depth = D > 0: behave like a sweep split into launches of D
+    iterations whose destinations alternate as libsoda_hip's do (soda_hip.cpp:
+    build_schedule): unless final_only, every second launch counted from the end
+    writes ITS level's (larger) box into dst too."""
     self.spec = spec
     self.oracle = soda_oracle.Oracle(spec)
+    self.launch_depth = launch_depth
 
-  def sweep(self, src, dst, local_dims, iterations, valid_lo, valid_hi, rows=None):
+  def sweep(self, src, dst, local_dims, iterations, valid_lo, valid_hi, rows=None,
+            final_only=False):
     spec = self.spec
     name_in = spec['inputs'][0]['name']
     name_out = spec['outputs'][0]
@@ -47,6 +53,15 @@ class OracleEngine:
                  for n, (lo, hi) in boxes[k].items()}
       self.oracle._call(arrays, tuple(local_dims), shifted)
       cur = out
+      d = self.launch_depth
+      if d and (k + 1) % d == 0 and k + 1 < iterations and not final_only:
+        m = -(-iterations // d)             # launches of this sweep
+        i = (k + 1) // d - 1                # the launch that just ended
+        if (m - 1 - i) % 2 == 0:            # its destination is `out`
+          lo, hi = boxes[k][name_out]
+          box = tuple(slice(vl - l, n - vh - h) for l, h, vl, vh, n in reversed(list(
+              zip(lo, hi, valid_lo, valid_hi, local_dims))))
+          dst[box] = torch.from_numpy(cur)[box]
     # like the kernels: only the valid box is written
     lo, hi = boxes[iterations - 1][name_out]
     box = tuple(slice(vl - l, n - vh - h) for l, h, vl, vh, n in reversed(list(zip(
@@ -62,7 +77,9 @@ class BandsFirst(sdist.SerialSchedule):
 
 def main():
   app, size, iterate, exchange, out_dir = sys.argv[1:6]
-  overlapped = len(sys.argv) > 6 and sys.argv[6] == 'overlap'
+  overlapped = len(sys.argv) > 6 and sys.argv[6].startswith('overlap')
+  # 'overlap:D': the CPU engine emulates launches of D iterations
+  launch_depth = int(sys.argv[6].split(':')[1]) if overlapped and ':' in sys.argv[6] else 0
   dims = [int(v) for v in size.split('x')]
   iterate, exchange = int(iterate), int(exchange)
   rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
@@ -89,12 +106,12 @@ def main():
     return ((0,) * len(dims), (0,) * len(dims)) if k == 0 else table[k - 1]
 
   order = BandsFirst() if overlapped else None
-  result, exchanges = sdist.run_slab(OracleEngine(spec), plan, [a, b, c], iterate,
-                                     margins_of, dist, schedule=order)
+  result, exchanges = sdist.run_slab(OracleEngine(spec, launch_depth), plan, [a, b, c],
+                                     iterate, margins_of, dist, schedule=order)
   own = result[plan.ghost_lo:plan.ghost_lo + plan.own].numpy().copy()
   # A was not written and now carries the neighbours' level-0 rows: a second
   # sweep may skip its first exchange and must give the same rows
-  again, fewer = sdist.run_slab(OracleEngine(spec), plan, [a, b, c], iterate,
+  again, fewer = sdist.run_slab(OracleEngine(spec, launch_depth), plan, [a, b, c], iterate,
                                 margins_of, dist, ghosts_ready=True, schedule=order)
   assert fewer == exchanges - 1, (fewer, exchanges)
   assert np.array_equal(again[plan.ghost_lo:plan.ghost_lo + plan.own].numpy(), own)

@@ -64,6 +64,28 @@ def test_null_arguments_are_errors_not_crashes(lib):
   assert lib.soda_hip_module_unload(None) == 0
 
 
+def test_c_and_python_slab_drivers_agree_on_the_exchange_period(lib):
+  """soda_hip_slab_exchange (what the generated `<app>_multi_gpu` uses) and
+  soda_hip.runtime.dist.SlabPlan clamp a too-deep ghost region to the same value and
+  refuse the same cuts."""
+  from soda_hip.runtime import dist as sdist
+  for rows in (3, 20, 64, 100, 2048, 16384):
+    for world in (1, 2, 3, 4, 8):
+      for r_lo, r_hi in ((1, 1), (2, 1), (0, 2), (0, 0), (3, 3)):
+        for wanted in (1, 5, 24, 100, 192):
+          got = ctypes.c_int(-1)
+          rc = lib.soda_hip_slab_exchange(rows, world, r_lo, r_hi, wanted,
+                                          ctypes.byref(got))
+          try:
+            want = sdist.SlabPlan([64, rows], 0, world, r_lo, r_hi, wanted).exchange
+          except ValueError:
+            want = None
+          if want is None:
+            assert rc == -8 and b'thinner than the stencil reach' in lib.soda_hip_last_error()
+          else:
+            assert rc == 0 and got.value == want, (rows, world, r_lo, r_hi, wanted)
+
+
 def test_no_gpu_means_loud_failure_not_fallback(lib):
   if host.device_count() > 0:
     pytest.skip('a GPU is present')

@@ -86,6 +86,12 @@ def test_reference_flags_are_accepted():
   meta = kernel_common.read_meta_from_source(r.stdout)
   assert meta['spec']['iterate'] == 3 and meta['spec']['tile_size'] == [2000, 0]
   assert meta['spec']['burst_width'] == 256
+  # the FPGA knobs are carried but unused, and sodac says so (once, as a warning)
+  assert 'ignores --unroll-factor, --tile-size, --dram-in, --dram-out' in r.stderr
+  assert r.stderr.count('WARNING') == 1
+  quiet = run_sodac(os.path.join(SAMPLES, 'jacobi2d.soda'), '--iterate', '3',
+                    '--hip-kernel', '-')
+  assert quiet.returncode == 0 and 'WARNING' not in quiet.stderr
 
 
 @pytest.mark.parametrize('app', APPS)

@@ -33,7 +33,7 @@ def run_world(tmp_path, world, app, dims, iterate, exchange, overlap=False):
     procs.append(subprocess.Popen(
         [sys.executable, os.path.join(ROOT, 'tests', 'dist_worker.py'), app,
          'x'.join(map(str, dims)), str(iterate), str(exchange), str(tmp_path)] +
-        (['overlap'] if overlap else []),
+        (['overlap' if overlap is True else 'overlap:%d' % overlap] if overlap else []),
         env=dict(env, RANK=str(rank), LOCAL_RANK=str(rank))))
   for p in procs:
     assert p.wait(timeout=300) == 0
@@ -76,6 +76,14 @@ def run_world(tmp_path, world, app, dims, iterate, exchange, overlap=False):
     (3, 'jacobi2d', (48, 90), 8, 3, True),
     (3, 'blur', (70, 75), 6, 2, True),
     (3, 'jacobi3d', (20, 18, 60), 6, 2, True),
+    # ... with super-steps of 3 and 4 LAUNCHES (overlap = launch depth of the CPU
+    # engine): the intermediate launches of a piece must not write the shared array
+    (2, 'jacobi2d', (40, 120), 13, 6, 2),
+    (3, 'jacobi2d', (40, 150), 12, 8, 2),
+    (3, 'jacobi3d', (20, 18, 90), 7, 6, 2),
+    (3, 'blur', (60, 110), 9, 6, 2),
+    # slabs too thin to cut bands from (10 own rows, 3 + 3 to send)
+    (3, 'jacobi2d', (48, 30), 8, 3, True),
 ])
 def test_slabs_match_single_process(tmp_path, world, app, dims, iterate, exchange,
                                     overlap):
