@@ -175,7 +175,12 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
     'const char* blob, int iterate, int ngpu) {\n' % (app, name_in, name_out))
   w('  const int dim = %d, last = dim - 1;\n' % dim)
   w('  int count = 0;\n  soda_hip_device_count(&count);\n')
-  w('  if (ngpu > count) ngpu = count;\n')
+  # rehearsal: every rank on the devices that exist (rank % count).  RCCL refuses two
+  # ranks on one GPU, so this only works over a stand-in for it (tests/rccl_standin);
+  # it lets the slab logic of this function run on a one-GPU box.
+  w('  const bool rehearse = getenv("SODA_HIP_REHEARSE_RANKS_ON_ONE_GPU") != nullptr;\n')
+  w('  if (count < 1) return SODA_HIP_ERR_NO_DEVICE;\n')
+  w('  if (ngpu > count && !rehearse) ngpu = count;\n')
   w('  if (ngpu < 1) return SODA_HIP_ERR_NO_DEVICE;\n')
   w('  buffer_t* in = var_%s_buffer; buffer_t* out = var_%s_buffer;\n'
     % (name_in, name_out))
@@ -183,7 +188,7 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
   w('  if (rows < ngpu) ngpu = (int)rows;\n')
   w('  std::vector<ncclComm_t> comms(ngpu, nullptr);\n')
   w('  if (ngpu > 1) {\n    std::vector<int> devs(ngpu);\n'
-    '    for (int i = 0; i < ngpu; ++i) devs[i] = i;\n'
+    '    for (int i = 0; i < ngpu; ++i) devs[i] = i % count;\n'
     '    if (ncclCommInitAll(comms.data(), ngpu, devs.data()) != ncclSuccess) {\n'
     '      fprintf(*error_report, "ERROR: ncclCommInitAll failed\\n");\n'
     '      return SODA_HIP_ERR_NO_DEVICE;\n    }\n  }\n')
@@ -213,7 +218,7 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
   w('    soda_hip_slab slab;\n    memset(&slab, 0, sizeof slab);\n')
   w('    int64_t local[4] = {1, 1, 1, 1}, ghost_lo = 0, ghost_hi = 0, own = 0;\n')
   w('    size_t row_bytes = 0;\n')
-  w('    rc = soda_hip_set_device(rank);\n')
+  w('    rc = soda_hip_set_device(rank % count);\n')
   w('    if (!rc) rc = soda_hip_module_load_file(blob, &module);\n')
   w('    soda_hip_program program;\n    fill_program(&program);\n')
   w('    soda_hip_kernel kernels[32];\n    const int n_kernels = fill_kernels(kernels);\n')

@@ -1,0 +1,120 @@
+"""Worker of test_run_slab_with_two_and_three_ranks_over_the_rccl_standin: runs
+soda_hip_run_slab (the C slab driver: ncclSend / ncclRecv groups + sweeps) with
+`world` ranks as host threads of THIS process on the box's one GPU, over the
+test-only librccl stand-in (tests/rccl_standin).  No torch here: the stand-in must be
+the first object with soname librccl.so in the process, so that libsoda_hip's
+dlopen("librccl.so") resolves to it."""
+import ctypes
+import os
+import sys
+import threading
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'soda-compiler_amd')):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+
+def main():
+  standin_path, app, size, world, iterate, wanted, out_dir = sys.argv[1:8]
+  dims = [int(v) for v in size.split('x')]
+  world, iterate, wanted = int(world), int(iterate), int(wanted)
+  standin = ctypes.CDLL(standin_path, mode=ctypes.RTLD_GLOBAL)
+  from soda_hip import frontend
+  from soda_hip.codegen import spec as specmod
+  from soda_hip.runtime import capi, host
+  hip = ctypes.CDLL('libamdhip64.so')
+  sample = os.path.join(ROOT, 'tests', 'samples', app + '.soda')
+  if not os.path.exists(sample):
+    sample = os.path.join(ROOT, 'tests', 'samples', 'extra', app + '.soda')
+  spec = specmod.spec_from_stencil(frontend.load(sample))
+  blob = os.path.join(ROOT, 'soda-compiler_amd', 'blobs', app + '.hsaco')
+  lib = capi.lib()
+  dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
+  rng = np.random.default_rng(99)
+  shape = tuple(reversed(dims))
+  full = rng.random(shape, dtype=np.float32).astype(dt) if dt.kind == 'f' else \
+      rng.integers(0, 65536, size=shape).astype(dt)
+  rows = dims[-1]
+  r_lo, r_hi = spec['radius']['lo'][-1], spec['radius']['hi'][-1]
+  exchange = ctypes.c_int()
+  capi.check(lib.soda_hip_slab_exchange(rows, world, r_lo, r_hi, wanted,
+                                        ctypes.byref(exchange)))
+  comms = (ctypes.c_void_p * world)()
+  assert standin.ncclCommInitAll(comms, world, None) == 0
+  base, extra = divmod(rows, world)
+  errors, results = [None] * world, [None] * world
+
+  def rank_main(rank):
+    try:
+      prog = host.open_program(blob=blob, spec=spec)   # one plan per host thread
+      stream = ctypes.c_void_p()
+      assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
+      slab = capi.Slab()
+      slab.rank, slab.world = rank, world
+      slab.reach_lo, slab.reach_hi = r_lo, r_hi
+      slab.exchange = exchange.value
+      for d, n in enumerate(dims):
+        slab.dims[d] = n
+      slab.own_first = rank * base + min(rank, extra)
+      slab.own_last = slab.own_first + base + (1 if rank < extra else 0)
+      local = (ctypes.c_int64 * 4)()
+      g_lo, g_hi = ctypes.c_int64(), ctypes.c_int64()
+      capi.check(lib.soda_hip_slab_extent(prog.handle, ctypes.byref(slab), local,
+                                          ctypes.byref(g_lo), ctypes.byref(g_hi)))
+      local_shape = (local[len(dims) - 1],) + shape[1:]
+      nbytes = int(np.prod(local_shape)) * dt.itemsize
+      arrays = [host.DeviceArray(nbytes) for _ in range(3)]
+      slab_in = np.zeros(local_shape, dtype=dt)
+      own = slab.own_last - slab.own_first
+      slab_in[g_lo.value:g_lo.value + own] = full[slab.own_first:slab.own_last]
+      arrays[0].upload(slab_in)
+      arrays[1].zero()
+      arrays[2].zero()
+      capi.check(lib.soda_hip_stream_synchronize(None))
+      result, count = ctypes.c_void_p(), ctypes.c_int()
+      capi.check(lib.soda_hip_run_slab(
+          prog.handle, ctypes.byref(slab), comms[rank], arrays[0].ptr, arrays[1].ptr,
+          arrays[2].ptr, iterate, stream, ctypes.byref(result), ctypes.byref(count)))
+      capi.check(lib.soda_hip_stream_synchronize(stream))
+      which = [a for a in arrays if a.ptr == result.value][0]
+      out = which.download(local_shape, dt)
+      results[rank] = (slab.own_first, slab.own_last, count.value,
+                       out[g_lo.value:g_lo.value + own].copy())
+      prog.close()
+    except BaseException as e:   # noqa: BLE001 - reported by the parent
+      errors[rank] = e
+      # peers blocked in the exchange must not hang: abort the group
+      standin.ncclCommAbort(ctypes.c_void_p(comms[rank]))
+      comms[rank] = None
+
+  threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=300)
+  if any(t.is_alive() for t in threads):
+    print('a rank is still blocked after 300 s', file=sys.stderr)
+    os._exit(3)
+  for rank, e in enumerate(errors):
+    if e is not None:
+      print('rank %d: %r' % (rank, e), file=sys.stderr)
+  if any(e is not None for e in errors):
+    sys.exit(2)
+  messages, nbytes = ctypes.c_longlong(), ctypes.c_longlong()
+  standin.rccl_standin_traffic(ctypes.c_void_p(comms[0]), ctypes.byref(messages),
+                               ctypes.byref(nbytes))
+  for rank, (first, last, count, own) in enumerate(results):
+    np.save(os.path.join(out_dir, 'rank%d.npy' % rank), own)
+    with open(os.path.join(out_dir, 'rank%d.txt' % rank), 'w') as f:
+      f.write('%d %d %d %d %d %d\n' % (first, last, exchange.value, count,
+                                       messages.value, nbytes.value))
+  for c in comms:
+    if c:
+      standin.ncclCommDestroy(ctypes.c_void_p(c))
+
+
+if __name__ == '__main__':
+  main()

@@ -514,6 +514,47 @@ def test_generated_cpp_host_multi_gpu_entry(tmp_path, app, dims, iterate):
   assert 'INFO: PASS!' in r.stderr
 
 
+@pytest.mark.parametrize('app,dims,iterate,ranks', [
+    ('jacobi2d', [700, 900], '70', '2'), ('jacobi2d', [500, 400], '40', '3'),
+    ('heat3d', [60, 50, 90], '7', '3')])
+def test_generated_cpp_host_multi_gpu_entry_with_several_ranks(tmp_path, app, dims,
+                                                               iterate, ranks):
+  """`<app>_multi_gpu` with 2 and 3 ranks: one thread per rank, ncclCommInitAll, the
+  rendezvous before the first message, soda_hip_run_slab, the valid interior written
+  back slab by slab - on this box's ONE GPU (SODA_HIP_REHEARSE_RANKS_ON_ONE_GPU) over
+  the test-only librccl stand-in.  The reference's own self-check (CPU golden loops of
+  the same generated file) must say PASS."""
+  import subprocess
+  import sys
+  from conftest import ROOT
+  standin = build_rccl_standin(tmp_path)
+  sodac = os.path.join(ROOT, 'soda-compiler_amd', 'sodac')
+  csrc = os.path.join(ROOT, 'soda-compiler_amd', 'csrc')
+  src = tmp_path / (app + '_host.cpp')
+  subprocess.check_call([sys.executable, sodac,
+                         os.path.join(ROOT, 'tests', 'samples', app + '.soda'),
+                         '--hip-host-cpp', str(src)])
+  exe = tmp_path / (app + '_host')
+  # librccl.so of the link line AND of libsoda_hip's dlopen is the stand-in: first on
+  # the library path of this one child process
+  subprocess.check_call(['g++', '-std=c++17', '-O1', '-fopenmp', '-ffp-contract=off',
+                         '-DSODA_HIP_MAIN', '-DSODA_HIP_MULTI_GPU',
+                         '-D__HIP_PLATFORM_AMD__', '-I', '/opt/rocm/include',
+                         '-I', os.path.join(ROOT, 'include'), str(src), '-L', csrc,
+                         '-lsoda_hip', '-L', str(tmp_path), '-lrccl', '-lpthread',
+                         '-Wl,-rpath,' + csrc, '-Wl,-rpath,' + str(tmp_path),
+                         '-Wl,-rpath,/opt/rocm/lib', '-o', str(exe)])
+  blob = os.path.join(gpu_util.BLOBS, app + '.hsaco')
+  env = dict(os.environ, SODA_ITERATE=iterate, SODA_GPUS=ranks,
+             SODA_HIP_REHEARSE_RANKS_ON_ONE_GPU='1',
+             LD_LIBRARY_PATH=str(tmp_path) + ':' + os.environ.get('LD_LIBRARY_PATH', ''))
+  r = subprocess.run([str(exe), blob] + [str(d) for d in dims], capture_output=True,
+                     text=True, env=env, timeout=600)
+  assert r.returncode == 0, r.stderr[-2000:]
+  assert 'INFO: PASS!' in r.stderr
+  assert os.path.basename(standin) == 'librccl.so'
+
+
 def test_run_slab_c_entry_with_one_rank():
   """soda_hip_run_slab / soda_hip_slab_extent (the slab driver below Python) with
   world = 1: same result as a plain sweep; a slab thinner than its ghost regions
@@ -978,6 +1019,69 @@ def test_multi_process_slabs_on_one_gpu(tmp_path, app, dims, world, iterate, exc
   sl = orc.valid_slices(tuple(dims), iterate)
   assert want[sl].size > 0 and np.array_equal(got[sl], want[sl])
   assert min(n_exchanges) >= -(-iterate // exchange)
+
+
+def build_rccl_standin(tmp_path):
+  """tests/rccl_standin: ncclSend / ncclRecv / groups for ranks that are threads of
+  one process on one GPU (a TEST library; soname librccl.so so that libsoda_hip's
+  dlopen resolves to it inside the worker process only)."""
+  import subprocess
+  from conftest import ROOT
+  out = os.path.join(str(tmp_path), 'librccl.so')
+  subprocess.check_call([
+      'g++', '-O1', '-fPIC', '-shared', '-std=c++17', '-Wl,-soname,librccl.so',
+      '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include',
+      os.path.join(ROOT, 'tests', 'rccl_standin', 'rccl_standin.cpp'), '-o', out,
+      '-L/opt/rocm/lib', '-Wl,-rpath,/opt/rocm/lib', '-lamdhip64', '-lpthread'])
+  return out
+
+
+@pytest.mark.parametrize('app,dims,world,iterate,exchange', [
+    ('jacobi2d', (1300, 900), 2, 70, 24),
+    ('jacobi2d', (700, 1500), 3, 100, 60),     # three launches per super-step
+    ('skew2d', (900, 800), 3, 30, 8),          # ghost regions 2 rows deep per iteration
+                                               # on one side, 1 on the other
+    ('jacobi3d', (130, 70, 200), 2, 20, 8),
+    ('jacobi3d', (140, 150, 90), 3, 9, 100)])  # period clamped to the smallest slab
+def test_run_slab_with_two_and_three_ranks_over_the_rccl_standin(tmp_path, app, dims,
+                                                                 world, iterate, exchange):
+  """soda_hip_run_slab - the C slab driver: ncclSend / ncclRecv inside one group per
+  super-step on the caller's stream, then the sweep - with world > 1.  RCCL refuses two
+  ranks on one GPU and this box has one, so the ranks are host threads over a
+  test-only stand-in for librccl.so (stream-ordered device-to-device copies matched
+  through a mailbox).  Own rows put together equal the oracle bit for bit; the
+  stand-in's counters prove that the ghost rows really travelled."""
+  import subprocess
+  import sys
+  from conftest import ROOT
+  from soda_hip.codegen import spec as specmod
+  standin = build_rccl_standin(tmp_path)
+  r = subprocess.run(
+      [sys.executable, os.path.join(ROOT, 'tests', 'rccl_standin_worker.py'), standin,
+       app, 'x'.join(map(str, dims)), str(world), str(iterate), str(exchange),
+       str(tmp_path)], capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stderr[-2000:]
+  spec = gpu_util.load_spec(app, iterate=iterate)
+  dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
+  rng = np.random.default_rng(99)
+  shape = tuple(reversed(dims))
+  full = rng.random(shape, dtype=np.float32).astype(dt)
+  orc = gpu_util.make_oracle(gpu_util.load_spec(app))
+  want = orc.run([full], iterate=iterate)[spec['outputs'][0]]
+  got = np.zeros_like(want)
+  for rank in range(world):
+    first, last, period, count, messages, nbytes = map(int, open(
+        os.path.join(tmp_path, 'rank%d.txt' % rank)).read().split())
+    got[first:last] = np.load(os.path.join(tmp_path, 'rank%d.npy' % rank))
+    assert count == -(-iterate // period)
+  sl = orc.valid_slices(tuple(dims), iterate)
+  assert want[sl].size > 0 and np.array_equal(got[sl], want[sl])
+  r_lo, r_hi = spec['radius']['lo'][-1], spec['radius']['hi'][-1]
+  row_bytes = int(np.prod(dims[:-1])) * dt.itemsize
+  # per exchange and interior boundary: period * r_lo rows up and period * r_hi down
+  # (a one-sided window sends nothing one way)
+  assert messages == count * (world - 1) * ((r_lo > 0) + (r_hi > 0))
+  assert nbytes == count * (world - 1) * period * (r_lo + r_hi) * row_bytes
 
 
 def test_bench_py_as_the_driver_launches_it_for_two_gpus():
