@@ -100,35 +100,34 @@ def make_input(spec, dims, rows=None):
 
 
 def cpu_baseline(spec, dims, budget_s):
-  """The CPU oracle on this host: a bounded number of whole-grid sweeps."""
+  """The CPU oracle on this host: a bounded number of whole-grid sweeps, OpenMP
+  team = the CPUs the cgroup grants (a box can show 256 logical CPUs and grant 16:
+  more threads than the quota only time-slice), three samples, the MEDIAN reported
+  with the spread beside it (shared hosts are noisy; round 2's single best-of-teams
+  figure moved 3.5x between runs)."""
   from oracle import soda_oracle
   orc = soda_oracle.Oracle(spec, flags=('-O3', '-march=native'))
   inputs = make_input(spec, dims)
-  # The box may show far more logical CPUs than its cgroup grants (256 vs a
-  # quota of 16 on the round-1 boxes; 256 threads then run 30x slower than 32).
-  # Try team sizes around the quota, keep the fastest.
   quota = orc.cpu_quota()
   logical = len(os.sched_getaffinity(0))
-  best = None
-  for threads in sorted({max(1, quota // 2), quota, min(logical, quota * 2),
-                         min(logical, quota * 4)}):
-    orc.set_threads(threads)
-    for _ in range(2):      # shared hosts are noisy: best of two short trials
-      t, u = orc.time_iterations(inputs, 3, warmup=1)
-      if best is None or u / t > best[1]:
-        best = (threads, u / t, t / 3)
-  threads, _, per = best
-  orc.set_threads(threads)
-  n = int(max(8, min(400, budget_s / max(per, 1e-6))))
-  t, u = orc.time_iterations(inputs, n, warmup=2)
-  return dict(value=u / t / 1e9, unit='Gcell-updates/s',
-              cores=threads, kind='port',
-              sample='%d full-grid sweeps of %s (iterations 3..%d of the run), '
-                     'OpenMP team of %d (cgroup quota %d of %d logical CPUs; best '
-                     'of the team sizes tried), g++ -O3 -march=native '
-                     '-ffp-contract=off; %.2f s' % (
-                         n, 'x'.join(map(str, dims)), n + 2, threads, quota,
-                         logical, t))
+  orc.set_threads(quota)
+  t, u = orc.time_iterations(inputs, 2, warmup=1)      # sizes the samples
+  per = t / 2
+  n = int(max(3, min(5000, budget_s / 3.0 / max(per, 1e-6))))
+  samples, seconds = [], 0.0
+  for _ in range(3):
+    t, u = orc.time_iterations(inputs, n, warmup=1)
+    samples.append(u / t / 1e9)
+    seconds += t
+  samples.sort()
+  median = samples[1]
+  return dict(value=median, unit='Gcell-updates/s', cores=quota, kind='port',
+              samples=samples, spread=(samples[-1] - samples[0]) / median,
+              sample='median of 3 samples of %d full-grid sweeps of %s each '
+                     '(iterations 2..%d of the run), OpenMP team of %d = the cgroup '
+                     'quota (%d logical CPUs), g++ -O3 -march=native '
+                     '-ffp-contract=off; %.2f s in all' % (
+                         n, 'x'.join(map(str, dims)), n + 1, quota, logical, seconds))
 
 
 def measured_traffic(kernel, dims, iterate):
@@ -141,6 +140,22 @@ def measured_traffic(kernel, dims, iterate):
   import glob
   files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
   for path in reversed(files):
+    with open(path) as f:
+      data = json.load(f)
+    for entry in data.get('entries', []):
+      if entry['kernel'] == kernel and list(entry['dims']) == list(dims) and \
+          entry['iterate'] == iterate:
+        return entry, os.path.basename(path)
+  return None, None
+
+
+def measured_counters(kernel, dims, iterate):
+  """SQ counters of `kernel` on this grid from the newest committed PMC passes
+  (profiles/rNN_sq_counters.json, tools/sq_counters.sh + collect_profiles.py):
+  VALU issue utilisation and where a wavefront spends its life."""
+  import glob
+  for path in reversed(sorted(glob.glob(os.path.join(ROOT, 'profiles',
+                                                     'r*_sq_counters.json')))):
     with open(path) as f:
       data = json.load(f)
     for entry in data.get('entries', []):
@@ -173,9 +188,21 @@ def per_iteration_updates(spec, dims, iterate, rows=None):
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 
 
-def roofline_block(spec, program, schedule, updates, timing, dims, iterate):
+# MI355X_MICROARCH.md: 6.29 TB/s measured for a float4 copy = what "all of HBM" looks
+# like from a kernel; used only to compare how BUSY the two limits are
+HBM_ACHIEVABLE_FRAC = 6.29 / 8.0
+
+
+def roofline_block(spec, program, schedule, updates, timing, dims, iterate,
+                   step_us=None):
   """`schedule` = [(kernel entry, modelled us)] as issued, `updates` = valid
-  cell-updates of each iteration of the sweep that `timing` timed.
+  cell-updates of each iteration of the sweep that `timing` timed; `step_us` = wall
+  time of one un-instrumented sweep (the timed loop).
+
+  Kernel time: every launch at the fastest of three event-bracketed repeats; events
+  between launches still add gaps, so when those launches sum to more than the
+  un-instrumented step took, they are scaled down to it (`kernel_time_scale` < 1):
+  a kernel is never reported longer than the step that contains it.
 
   The figures: `frac_algorithmic` is SURVEY.md 8(d)'s (algorithmic bytes per
   update x updates per launch / launch duration / 8 TB/s; > 1 means temporal
@@ -196,12 +223,15 @@ def roofline_block(spec, program, schedule, updates, timing, dims, iterate):
   if not per_launch:      # per-stage kernels: one iteration per group of launches
     per_launch = list(updates)
   upd = sum(per_launch) / len(per_launch)
-  avg_s = timing['dominant_us'] / max(1, timing['dominant_launches']) * 1e-6
+  scale = 1.0
+  if step_us and timing.get('fastest_us', 0) > step_us:
+    scale = step_us / timing['fastest_us']
+  avg_s = timing['dominant_us'] / max(1, timing['dominant_launches']) * 1e-6 * scale
   alg = upd * abytes / avg_s / 1e9
   ops = kernelmod.arithmetic_weight(spec)
   valu = upd * ops / avg_s / 1e12
   traffic, source = measured_traffic(name, dims, iterate)
-  block = dict(kernel=name, kernel_avg_us=avg_s * 1e6,
+  block = dict(kernel=name, kernel_avg_us=avg_s * 1e6, kernel_time_scale=scale,
                kernel_launches=timing['dominant_launches'],
                updates_per_launch=upd, algorithmic_bytes_per_update=abytes,
                algorithmic_GBps=alg, frac_algorithmic=alg / HBM_PEAK_GBPS,
@@ -223,7 +253,16 @@ def roofline_block(spec, program, schedule, updates, timing, dims, iterate):
     depth = max([e['depth'] for e, _ in schedule if e['name'] == name] or [1])
     hbm_frac = alg / max(1, depth) / HBM_PEAK_GBPS
     block['hbm_floor_frac'] = hbm_frac
-  if block['valu_frac'] > hbm_frac:
+  # Which limit binds: with SQ counters for this kernel on this grid, the busier of
+  # the two units (VALU issue utilisation against the share of the ACHIEVABLE HBM
+  # rate); without, the larger fraction of peak.
+  sq, sq_source = measured_counters(name, dims, iterate)
+  valu_binds = block['valu_frac'] > hbm_frac
+  if sq:
+    block.update(valu_issue_utilisation=sq['valu_issue_utilisation'],
+                 wave_parked=sq.get('wave_parked'), counters_source=sq_source)
+    valu_binds = sq['valu_issue_utilisation'] > hbm_frac / HBM_ACHIEVABLE_FRAC
+  if valu_binds:
     block.update(bound='valu', achieved=valu, peak=VALU_PEAK_TLANEOPS,
                  unit='Tlane-op/s', frac=block['valu_frac'])
   else:
@@ -271,8 +310,9 @@ def run_single(args):
     program.sweep(ip, op, dims, args.iterate)
   sync()
   wall = time.perf_counter() - t0
-  # the same loop once more under hipEvents, per launch, for the roofline entry
-  timing = program.sweep_timed(ip, op, dims, args.iterate, warmup=0, repeats=1)
+  # the same loop under hipEvents, per launch, for the roofline entry: three repeats,
+  # every launch at its fastest
+  timing = program.sweep_timed(ip, op, dims, args.iterate, warmup=0, repeats=3)
   schedule = program.schedule(dims, args.iterate)
   valid = specmod.valid_cells(spec, dims, args.iterate)
   nominal = cells * args.iterate
@@ -297,7 +337,7 @@ def run_single(args):
                   device=host.device_info(0)['arch']),
       roofline=roofline_block(spec, program, schedule,
                               per_iteration_updates(spec, dims, args.iterate),
-                              timing, dims, args.iterate))
+                              timing, dims, args.iterate, step_us=ms_per_step * 1e3))
   for d in din + dout:
     d.free()
   program.close()
@@ -328,7 +368,7 @@ def main():
   if args.gpus > 1 or world > 1 or args.force_dist:
     from soda_hip.runtime import dist
     result = dist.bench_main(args, open_program, make_input, per_iteration_updates,
-                             roofline_block, schedule_text)
+                             roofline_block, schedule_text, cpu_baseline)
   else:
     result = run_single(args)
   if result is not None:

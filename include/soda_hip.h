@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SODA_HIP_ABI_VERSION 3
+#define SODA_HIP_ABI_VERSION 4
 #define SODA_HIP_MAX_DIMS 4
 #define SODA_HIP_MAX_TENSORS 16 /* inputs + stages of one program */
 #define SODA_HIP_MAX_IO 8
@@ -163,6 +163,12 @@ typedef struct soda_hip_kernel {
   int32_t step_valu;  /* VALU issue cycles ONE workgroup (all its wavefronts
                          together) spends per streamed row / plane */
   int32_t step_bytes; /* HBM bytes one workgroup loads + stores per step */
+  int32_t step_ns_full; /* MEASURED nanoseconds per streamed step with the chip full of
+                           this kernel's workgroups, and ... */
+  int32_t step_ns_one;  /* ... with at most one workgroup per CU (tools/calibrate.py
+                           on an MI355X, carried in the blob's metadata; 0 = not
+                           calibrated: the scheduler prices the kernel with
+                           step_valu / step_bytes) */
   int32_t xcd_tiles;  /* N > 0: the kernel takes a 1-D grid and places its tiles
                          itself, XCD by XCD (N = most tiles per super-tile; 1 =
                          the plain round-robin deal): the launcher cuts the plane of tiles
@@ -213,9 +219,13 @@ typedef struct soda_hip_timing {
   double kernel_us;     /* device time of the timed sweep loop (hipEvents) */
   int32_t launches;     /* kernel launches in one sweep loop */
   int32_t max_depth;    /* deepest temporal block used */
-  double dominant_us;   /* summed device time of the dominant kernel ... */
-  int32_t dominant_launches; /* ... over this many launches */
+  double dominant_us;   /* device time of the dominant kernel's launches in ONE sweep
+                           loop, every launch at its fastest of the repeats ... */
+  int32_t dominant_launches; /* ... over this many launches (of one sweep loop) */
   char dominant_name[96];
+  double fastest_us;    /* all launches of one sweep loop, each at its fastest repeat
+                           (per-launch events add gaps: compare with the wall time of
+                           an un-instrumented loop before quoting a kernel time) */
 } soda_hip_timing;
 
 /* The device sweep: `iterate` applications of the program on device arrays.

@@ -151,15 +151,44 @@ def flags_from_text(text):
   return []
 
 
+# Issue cost of an operation in units of one f32 add (2 SIMD cycles per wave64
+# instruction on gfx950).  Double precision runs at half the rate; a double division
+# and a double square root compile to ~13 double instructions each (denoise2d's
+# `1.0f / sqrt(...)`: 12 v_fma_f64, 3 v_mul_f64, 2 v_div_scale_f64, v_rsq_f64,
+# v_rcp_f64, v_div_fmas_f64, v_div_fixup_f64, 2 v_ldexp_f64, 2 conversions per cell);
+# a float division to ~10 single ones; an integer division by a literal to a
+# multiply-high and shifts.  Other math calls are the double library functions.
+OP_COST = dict(f32=1, f64=2, div_f32=10, div_f64=30, div_int=8, sqrt=30, cheap_call=4,
+               call=60)
+_CHEAP_CALLS = ('fabs', 'fmax', 'fmin', 'floor', 'ceil', 'trunc', 'round', 'rint',
+                'nearbyint', 'copysign', 'abs', 'min', 'max', 'select')
+
+
 def arithmetic_weight(spec):
-  """Rough VALU cost of one iteration per cell: operators of all stages,
-  divisions and math calls weighted 8."""
+  """VALU cost of one iteration per cell, in f32-add equivalents: the operators of
+  all stages priced by OP_COST.  An expression is priced as DOUBLE arithmetic when
+  it holds a double literal, a math call (the C double functions) or a
+  double tensor - as the C++ promotion rules make (most of) it."""
+  types = specmod.tensor_c_types(spec)
   weight = 0
   for stage in spec['stages']:
-    for text in [let['expr'] for let in stage['lets']] + [stage['expr']]:
-      text = re.sub(r'\{[^}]*\}', 'L', kernel_common.device_expr(text))
-      weight += len(re.findall(r'(?<=[\w)\s])[-+*](?=[\s\w(])', text))
-      weight += 8 * (text.count('/') + len(re.findall(r'soda_fn_\w+', text)))
+    texts = [(let['c_type'], let['expr']) for let in stage['lets']] + \
+        [(stage['c_type'], stage['expr'])]
+    for c_type, source in texts:
+      operands = [types.get(t) for t, _ in specmod.LOAD_RE.findall(source)]
+      text = re.sub(r'\{[^}]*\}', 'L', kernel_common.device_expr(source))
+      calls = re.findall(r'soda_fn_(\w+)', text)
+      heavy = [c for c in calls if c not in _CHEAP_CALLS]
+      double = c_type == 'double' or 'double' in operands or bool(heavy) or \
+          bool(_DOUBLE_LITERAL.search(text))
+      integer = not double and c_type not in ('float', 'double', '_Float16')
+      unit = OP_COST['f64'] if double else OP_COST['f32']
+      weight += unit * len(re.findall(r'(?<=[\w)\s])[-+*](?=[\s\w(])', text))
+      weight += text.count('/') * OP_COST[
+          'div_f64' if double else 'div_int' if integer else 'div_f32']
+      for c in calls:
+        weight += OP_COST['sqrt'] if c == 'sqrt' else \
+            OP_COST['cheap_call'] if c in _CHEAP_CALLS else OP_COST['call']
   return weight
 
 

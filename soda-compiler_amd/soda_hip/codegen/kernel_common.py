@@ -12,7 +12,7 @@ import re
 
 from . import spec as specmod
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # element types as builtin spellings (no <stdint.h> in the translation unit)
 BUILTIN_TYPE = {

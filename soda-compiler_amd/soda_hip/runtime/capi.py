@@ -11,7 +11,7 @@ MAX_TENSORS = 16
 MAX_IO = 8
 MAX_WINDOWS = 64
 MAX_KERNELS = 32
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 KERNEL_STAGE = 0
 KERNEL_FUSED = 1
@@ -44,6 +44,7 @@ class KernelDesc(ctypes.Structure):
               ('fill_rows', ctypes.c_int32), ('origin_align', ctypes.c_int32),
               ('min_extent', ctypes.c_int32 * 2),
               ('step_valu', ctypes.c_int32), ('step_bytes', ctypes.c_int32),
+              ('step_ns_full', ctypes.c_int32), ('step_ns_one', ctypes.c_int32),
               ('xcd_tiles', ctypes.c_int32)]
 
 
@@ -59,7 +60,8 @@ class Timing(ctypes.Structure):
   _fields_ = [('kernel_us', ctypes.c_double), ('launches', ctypes.c_int32),
               ('max_depth', ctypes.c_int32), ('dominant_us', ctypes.c_double),
               ('dominant_launches', ctypes.c_int32),
-              ('dominant_name', ctypes.c_char * 96)]
+              ('dominant_name', ctypes.c_char * 96),
+              ('fastest_us', ctypes.c_double)]
 
 
 class BufferT(ctypes.Structure):

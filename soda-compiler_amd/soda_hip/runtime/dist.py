@@ -339,7 +339,7 @@ class TimedSerialSchedule(SerialSchedule):
 
 
 def bench_main(args, open_program, make_input, per_iteration_updates,
-               roofline_block, schedule_text):
+               roofline_block, schedule_text, cpu_baseline=None):
   """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`."""
   import torch
   import torch.distributed as dist
@@ -465,6 +465,11 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
                       device=host.device_info(local_rank)['arch']),
           roofline=roofline_block(spec, program, sched, updates, timing,
                                   plan.local_dims, first))
+      if cpu_baseline is not None and getattr(args, 'cpu_seconds', 0) > 0:
+        # the CPU figure beside every point of the curve: the same
+        # whole-grid workload on this host's cores, timed by rank 0 while the other
+        # ranks wait at the barrier below - outside the timed region
+        result['cpu_baseline'] = cpu_baseline(spec, dims, args.cpu_seconds)
       result['roofline']['note'] = (
           'rank 0, first super-step of %d iterations on its %d own rows + %d ghost '
           'rows; updates counted on own rows only' % (

@@ -186,6 +186,8 @@ def kernel_descs(table):
       d.min_extent[i] = v
     d.step_valu = int(k.get('step_valu', 0))
     d.step_bytes = int(k.get('step_bytes', 0))
+    d.step_ns_full = int(k.get('step_ns_full', 0))
+    d.step_ns_one = int(k.get('step_ns_one', 0))
     d.xcd_tiles = int(k.get('xcd_tiles', 0))
   return arr
 
@@ -290,7 +292,7 @@ class Program:
         self._dims(dims), iterate, warmup, repeats, stream, ctypes.byref(t)))
     return dict(kernel_us=t.kernel_us, launches=t.launches, max_depth=t.max_depth,
                 dominant_us=t.dominant_us, dominant_launches=t.dominant_launches,
-                dominant_name=t.dominant_name.decode())
+                dominant_name=t.dominant_name.decode(), fastest_us=t.fastest_us)
 
   # -- numpy conveniences (tests, <app>_test) --------------------------------
   def run_numpy(self, inputs, iterate=None, timed=False):
