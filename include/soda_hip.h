@@ -163,12 +163,15 @@ typedef struct soda_hip_kernel {
   int32_t step_valu;  /* VALU issue cycles ONE workgroup (all its wavefronts
                          together) spends per streamed row / plane */
   int32_t step_bytes; /* HBM bytes one workgroup loads + stores per step */
-  int32_t step_ns_full; /* MEASURED nanoseconds per streamed step with the chip full of
-                           this kernel's workgroups, and ... */
-  int32_t step_ns_one;  /* ... with at most one workgroup per CU (tools/calibrate.py
-                           on an MI355X, carried in the blob's metadata; 0 = not
-                           calibrated: the scheduler prices the kernel with
-                           step_valu / step_bytes) */
+  /* MEASURED figures of this kernel (tools/calibrate.py on an MI355X, kept in
+   * soda_hip/codegen/calibration.json and carried in the blob's metadata; all 0 =
+   * not calibrated: the scheduler prices the kernel with step_valu / step_bytes): */
+  int32_t step_ns_full; /* nanoseconds per streamed step with the chip full of this
+                           kernel's workgroups on arrays that fit the Infinity Cache
+                           (what the kernel's own pipeline costs) */
+  int32_t step_ns_one;  /* the same with at most one workgroup per CU */
+  int32_t stream_gbps;  /* GB/s of step_bytes the kernel sustains on arrays far larger
+                           than the caches (its HBM-bound rate) */
   int32_t xcd_tiles;  /* N > 0: the kernel takes a 1-D grid and places its tiles
                          itself, XCD by XCD (N = most tiles per super-tile; 1 =
                          the plain round-robin deal): the launcher cuts the plane of tiles

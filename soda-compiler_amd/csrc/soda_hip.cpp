@@ -249,13 +249,36 @@ const double kModelValuHz = 2.0e9;
 const double kModelHbmBytesPerSec = 4.6e12;
 const double kModelLaunchUs = 2.0;
 
-double step_seconds(const soda_hip_plan* plan, int k, double blocks) {
+// `footprint` = bytes of the arrays the launch streams (inputs + outputs of its box).
+// With calibration figures in the descriptor (soda_hip_kernel.step_ns_*,
+// stream_gbps): the kernel's own step time at the occupancy this grid reaches,
+// interpolated between one workgroup per CU and a full chip, or - on arrays beyond
+// the Infinity Cache - the time its HBM rate allows, whichever is longer.
+// The HBM term fades in between arrays that live in the 256 MiB Infinity Cache and
+// arrays several times its size (jacobi3d, one-level-per-wavefront kernel: 1.63 us per
+// step at 304^3 = 215 MiB in + out, the step time of a cache-resident array; 2.03 us at
+// 400^3 = 488 MiB; 2.41 us at 512^3).
+const double kCacheResidentBytes = 128.0 * 1024 * 1024;
+const double kStreamingBytes = 512.0 * 1024 * 1024;
+
+double step_seconds(const soda_hip_plan* plan, int k, double blocks, double footprint = 0) {
   const soda_hip_kernel& desc = plan->kernels[k];
-  if (desc.step_valu <= 0 && desc.step_bytes <= 0) return 0;
   const double cus = std::max(1, plan->cus);
-  double per_cu = std::max(1, plan->resident_blocks[k]) / cus;
+  const double full = std::max(1, plan->resident_blocks[k]) / cus;
   // a grid smaller than the chip holds: fewer workgroups share each CU
-  per_cu = std::min(per_cu, std::max(1.0, blocks / cus));
+  const double per_cu = std::min(full, std::max(1.0, blocks / cus));
+  if (desc.step_ns_full > 0 && desc.step_ns_one > 0) {
+    const double share = full > 1 ? (per_cu - 1) / (full - 1) : 1.0;
+    double t = (desc.step_ns_one + (desc.step_ns_full - desc.step_ns_one) * share) * 1e-9;
+    if (desc.stream_gbps > 0 && desc.step_bytes > 0 && footprint > kCacheResidentBytes) {
+      const double weight = std::min(1.0, (footprint - kCacheResidentBytes) /
+                                              (kStreamingBytes - kCacheResidentBytes));
+      t = std::max(t, weight * std::min(blocks, full * cus) * desc.step_bytes /
+                          (desc.stream_gbps * 1e9));
+    }
+    return t;
+  }
+  if (desc.step_valu <= 0 && desc.step_bytes <= 0) return 0;
   const double valu = per_cu * desc.step_valu / 4.0 / kModelValuHz;
   const double hbm = per_cu * cus * desc.step_bytes / kModelHbmBytesPerSec;
   return std::max(valu, hbm);
@@ -315,8 +338,17 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
       out->args.param[0] = best;
       const double blocks = (double)inner * (double)((extent + best - 1) / best);
       const double rounds = std::ceil(blocks / (double)resident);
+      double footprint = 0;      // bytes the launch streams: its box, in and out
+      {
+        double cells = 1;
+        for (int e = 0; e < dim; ++e) cells *= (double)(args.box_hi[e] - args.box_lo[e]);
+        const soda_hip_program& p = plan->prog;
+        for (int j = 0; j < p.n_inputs; ++j) footprint += cells * p.elem_size[j];
+        for (int j = 0; j < p.n_outputs; ++j)
+          footprint += cells * p.elem_size[p.output_tensor[j]];
+      }
       out->est_us = kModelLaunchUs + rounds * (double)(best + desc.fill_rows) *
-                                         step_seconds(plan, k, blocks) * 1e6;
+                                         step_seconds(plan, k, blocks, footprint) * 1e6;
     }
     int64_t g = (extent + tile - 1) / tile;
     if (d > 0 && desc.kind == SODA_HIP_KERNEL_STAGE && (g > 65535 || dim > 3)) {
@@ -1135,10 +1167,12 @@ int soda_hip_sweep_timed(soda_hip_plan* plan, void* const* in, void* const* out,
       for (size_t i = 0; i < list.size(); ++i) {
         const soda_hip_args& a = list[i].args;
         fprintf(stderr, "soda_hip: launch %3zu %-28s %8.1f us (model %7.1f)  box %lld x %lld x %lld  "
-                "grid %u x %u x %u  chunk %lld\n", i, plan->kernels[list[i].kernel].name,
+                "grid %u x %u x %u  chunk %lld  fill %d  resident %d\n", i,
+                plan->kernels[list[i].kernel].name,
                 fastest[i] * 1000.0, list[i].est_us, (long long)(a.box_hi[0] - a.box_lo[0]),
                 (long long)(a.box_hi[1] - a.box_lo[1]), (long long)(a.box_hi[2] - a.box_lo[2]),
-                list[i].grid[0], list[i].grid[1], list[i].grid[2], (long long)a.param[0]);
+                list[i].grid[0], list[i].grid[1], list[i].grid[2], (long long)a.param[0],
+                plan->kernels[list[i].kernel].fill_rows, plan->resident_blocks[list[i].kernel]);
       }
     timing->kernel_us = total_ms * 1000.0 / repeats;
     timing->fastest_us = fastest_ms * 1000.0;

@@ -219,6 +219,38 @@ def fused_depths(spec, max_depth):
 WP_STEP_FIXED_CYCLES = 640
 
 
+CALIBRATION_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                'calibration.json')
+CALIBRATED_FIELDS = ('step_ns_full', 'step_ns_one', 'stream_gbps')
+_calibration = None
+
+
+def calibration_key(entry, spec):
+  """Identity of a generated kernel for the calibration table: the program it
+  computes and every figure of its table entry except the cost figures themselves -
+  a change of the generator that changes the kernel's shape makes its measurement
+  stale (the scheduler then falls back to the model) until tools/calibrate.py has
+  run again."""
+  import hashlib
+  import json
+  shape = {k: v for k, v in entry.items()
+           if k not in CALIBRATED_FIELDS + ('step_valu', 'step_bytes')}
+  digest = hashlib.sha1(json.dumps(shape, sort_keys=True).encode()).hexdigest()[:12]
+  return '%s/%s/%s' % (kernel_common.program_hash(spec)[:12], entry['name'], digest)
+
+
+def calibration():
+  global _calibration
+  if _calibration is None:
+    import json
+    try:
+      with open(CALIBRATION_FILE) as f:
+        _calibration = json.load(f).get('kernels', {})
+    except (OSError, ValueError):
+      _calibration = {}
+  return _calibration
+
+
 def annotate_cost(entry, spec):
   """Cost figures of a streaming kernel for the run-time scheduler
   (soda_hip_kernel.step_valu / step_bytes, include/soda_hip.h): VALU issue
@@ -249,6 +281,12 @@ def annotate_cost(entry, spec):
     cells_out = entry['tile'][0] * entry['tile'][1]
   entry['step_valu'] = int(valu)
   entry['step_bytes'] = int((n_in * cells_in + n_out * cells_out) * elem)
+  # measured step times of exactly this kernel, when it has been calibrated
+  # (soda_hip_kernel.step_ns_full / step_ns_one / stream_gbps)
+  measured = calibration().get(calibration_key(entry, spec))
+  if measured:
+    for field in CALIBRATED_FIELDS:
+      entry[field] = int(measured.get(field, 0))
   return entry
 
 
@@ -310,14 +348,28 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
             depth <= ALIGN_FULL_MAX_DEPTH and
             arithmetic_weight(spec) <= ALIGN_FULL_MAX_WEIGHT) else 'none'
       single = piped = None
-      if groups <= 1 or depth < WAVE_PIPELINE_MIN_DEPTH or groups == -1:
+      k1 = {k[3:]: v for k, v in fused_options.items() if k.startswith('k1_')}
+      if depth == 1 and k1.get('ring'):
+        # depth 1 through the LDS input ring: one wavefront per strip, rows arrive
+        # by LDS-direct loads (no prefetch registers), counted waits, one decision
+        # per strip about ragged stores (kernel_stream2d_wp with a single group)
+        try:
+          k1.setdefault('groups', 1)
+          k1.setdefault('vgpr_budget', 250)
+          piped = kernel_stream2d_wp.emit(spec, 1, **dict(common, **k1))
+        except kernel_stream2d.NotFusable as e:
+          notes.append('depth 1 not through the ring: %s' % e)
+      if piped is not None:
+        pass
+      elif groups <= 1 or depth < WAVE_PIPELINE_MIN_DEPTH or groups == -1:
         try:
           single = kernel_stream2d.emit(
               spec, depth, **common,
-              **{k: v for k, v in fused_options.items() if k not in WP_ONLY_OPTIONS})
+              **{k: v for k, v in fused_options.items()
+                 if k not in WP_ONLY_OPTIONS and not k.startswith('k1_')})
         except kernel_stream2d.NotFusable as e:
           notes.append('depth %d not fused: %s' % (depth, e))
-      want_piped = depth >= WAVE_PIPELINE_MIN_DEPTH and (
+      want_piped = piped is None and depth >= WAVE_PIPELINE_MIN_DEPTH and (
           groups > 1 or (groups == -1 and (
               single is None or single[1]['est_vgprs'] > AUTO_WP_VGPRS or
               (depth >= PACKED_FROM_DEPTH and kernel_stream2d_wp.packable(spec)))))

@@ -45,6 +45,7 @@ class KernelDesc(ctypes.Structure):
               ('min_extent', ctypes.c_int32 * 2),
               ('step_valu', ctypes.c_int32), ('step_bytes', ctypes.c_int32),
               ('step_ns_full', ctypes.c_int32), ('step_ns_one', ctypes.c_int32),
+              ('stream_gbps', ctypes.c_int32),
               ('xcd_tiles', ctypes.c_int32)]
 
 

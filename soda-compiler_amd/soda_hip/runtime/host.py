@@ -188,6 +188,7 @@ def kernel_descs(table):
     d.step_bytes = int(k.get('step_bytes', 0))
     d.step_ns_full = int(k.get('step_ns_full', 0))
     d.step_ns_one = int(k.get('step_ns_one', 0))
+    d.stream_gbps = int(k.get('stream_gbps', 0))
     d.xcd_tiles = int(k.get('xcd_tiles', 0))
   return arr
 

@@ -50,7 +50,7 @@ def test_abi_version_and_error_names(lib):
 def test_struct_layouts_match_the_header(lib):
   # soda_hip_args is what the generated kernels receive by value
   assert ctypes.sizeof(capi.BufferT) == 72          # legacy Halide buffer_t
-  assert ctypes.sizeof(capi.KernelDesc) == 96 + 4 * (3 + 3 + 4 + 1 + 3 + 2 + 2 + 1)
+  assert ctypes.sizeof(capi.KernelDesc) == 96 + 4 * (3 + 3 + 4 + 1 + 3 + 2 + 3 + 1)
   assert ctypes.sizeof(capi.Window) == 4 * (2 + 4 + 4)
   assert ctypes.sizeof(capi.ProgramDesc) == 4 * (4 + 16 + 8 + 1) + 64 * 40
 

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Measures, on the GPU box, the step times the run-time scheduler prices launches
+with (include/soda_hip.h: soda_hip_kernel.step_ns_full / step_ns_one / stream_gbps)
+for every fused streaming kernel of the sample programs, and writes them to
+soda_hip/codegen/calibration.json (keyed by program + kernel shape:
+kernel.calibration_key).  kernel.generate() puts the figures into the blob metadata;
+kernels without an entry are priced by the model (step_valu / step_bytes).
+
+Per kernel three single launches, each `depth` iterations of a blob that holds only
+that deep kernel:
+  * cache-resident array, chip full          -> step_ns_full
+  * cache-resident array, <= 1 workgroup/CU   -> step_ns_one  (forced long chunks)
+  * array far beyond the Infinity Cache       -> stream_gbps
+step = launch time / (rounds x (chunk + fill rows)), from the library's own launch
+trace (SODA_HIP_LAUNCH_TRACE).
+
+usage: calibrate.py [app ...]      (default: every sample with deep kernels)"""
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIZES = {   # (cache-resident, streaming) extents per dimension
+    2: (3072, 16384),
+    3: (256, 512),
+}
+APPS = ['jacobi2d', 'seidel2d', 'blur', 'sobel2d', 'jacobi3d', 'heat3d']
+TRACE = re.compile(r'launch\s+\d+ (\S+)\s+([\d.]+) us \(model\s+[\d.]+\)  box (\d+) x (\d+) x (\d+)  '
+                   r'grid (\d+) x (\d+) x (\d+)  chunk (\d+)  fill (\d+)  resident (\d+)')
+
+
+def child(app, depth, form, n, chunk):
+  sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd')]
+  import numpy as np
+  from soda_hip import frontend
+  from soda_hip.codegen import kernel, spec as specmod
+  from soda_hip.runtime import host
+  import __graft_entry__ as entry
+  iterate = entry.BLOB_ITERATE.get(app)
+  st = frontend.load(entry.sample_path(app), iterate=iterate)
+  spec = specmod.spec_from_stencil(st)
+  opts = dict(depths=[depth])
+  if form:
+    opts['deep3d'] = form
+  text, table = kernel.generate(spec, **opts)
+  mine = [k for k in table if k['kind'] == 'fused' and k['depth'] == depth]
+  if not mine:
+    print('NOKERNEL')
+    return
+  path = '/tmp/calib_%d.hsaco' % os.getpid()
+  kernel.compile_to_code_object(text, path)
+  prog = host.open_program(blob=path, spec=spec)
+  dims = [n] * spec['dim']
+  shape = tuple(reversed(dims))
+  dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
+  rng = np.random.default_rng(1)
+  a = rng.random(shape, dtype=np.float32).astype(dt) if dt.kind == 'f' else \
+      rng.integers(0, 65536, size=shape).astype(dt)
+  din = host.DeviceArray(a.nbytes)
+  din.upload(a)
+  dout = host.DeviceArray(a.nbytes)
+  dout.zero()
+  lowered = specmod.inline_pointwise(spec)
+  print('ENTRY ' + json.dumps(dict(key=kernel.calibration_key(mine[-1], lowered),
+                                   entry=mine[-1])))
+  # clocks settle only after tens of milliseconds of work: warm up that long first
+  # (un-traced), then time five repeats
+  os.environ.pop('SODA_HIP_LAUNCH_TRACE', None)
+  probe = prog.sweep_timed([din.ptr], [dout.ptr], dims, depth, warmup=1, repeats=1)
+  warm = int(min(2000, max(3, 80000.0 / max(1.0, probe['kernel_us']))))
+  os.environ['SODA_HIP_LAUNCH_TRACE'] = '1'
+  prog.sweep_timed([din.ptr], [dout.ptr], dims, depth, warmup=warm, repeats=5)
+  prog.close()
+
+
+def measure(app, depth, form, n, chunk=0):
+  env = dict(os.environ, SODA_HIP_TUNING='1', SODA_HIP_LAUNCH_TRACE='1')
+  if chunk:
+    env['SODA_HIP_CHUNK_ROWS'] = str(chunk)
+  p = subprocess.run([sys.executable, __file__, '--child', app, str(depth), form or '-',
+                      str(n), str(chunk)], env=env, capture_output=True, text=True)
+  m = re.search(r'ENTRY (.*)', p.stdout)
+  launches = TRACE.findall(p.stderr)
+  if not m or not launches:
+    return None
+  info = json.loads(m.group(1))
+  name, us, bx, by, bz, gx, gy, gz, chunk_used, fill, resident = launches[0]
+  blocks = int(gx) * int(gy) * int(gz)
+  rounds = -(-blocks // int(resident))
+  steps = rounds * (int(chunk_used) + int(fill))
+  return dict(info, name=name, us=float(us), blocks=blocks, resident=int(resident),
+              steps=steps, chunk=int(chunk_used),
+              # (the scheduler adds 2 us per launch on top of the steps)
+              step_ns=max(1.0, float(us) - 2.0) * 1e3 / steps)
+
+
+def main():
+  apps = sys.argv[1:] or APPS
+  sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd')]
+  from soda_hip import frontend
+  from soda_hip.codegen import kernel, spec as specmod
+  import __graft_entry__ as entry
+  path = kernel.CALIBRATION_FILE
+  try:
+    table = json.load(open(path))
+  except (OSError, ValueError):
+    table = dict(kernels={})
+  table['note'] = ('measured by tools/calibrate.py on one MI355X; keyed by program '
+                   'hash / kernel name / shape digest (kernel.calibration_key)')
+  for app in apps:
+    st = frontend.load(entry.sample_path(app), iterate=entry.BLOB_ITERATE.get(app))
+    spec = specmod.spec_from_stencil(st)
+    _, kernels = kernel.generate(spec)
+    dim = spec['dim']
+    small, big = SIZES[dim]
+    for k in kernels:
+      if k['kind'] != 'fused' or not k.get('fill_rows'):
+        continue
+      form = None
+      if dim == 3 and k['depth'] > 2:
+        form = 'blk' if k.get('stack') else 'wp'
+      full = measure(app, k['depth'], form, small)
+      if not full or full['name'] != k['name']:
+        print('%-28s not measured' % k['name'])
+        continue
+      # <= one workgroup per CU: chunks long enough that the grid is below 256
+      inner = max(1, full['blocks'] * full['chunk'] // max(1, small))
+      long_chunk = min(small, -(-small * inner // 240 // 4) * 4 + 4)
+      one = measure(app, k['depth'], form, small, chunk=max(8, long_chunk))
+      stream = measure(app, k['depth'], form, big)
+      if not one or not stream:
+        print('%-28s partly measured' % k['name'])
+        continue
+      active = min(stream['blocks'], stream['resident'])
+      gbps = active * k['step_bytes'] / stream['step_ns']      # bytes / ns = GB/s
+      table['kernels'][full['key']] = dict(
+          name=k['name'], app=app, step_ns_full=int(round(full['step_ns'])),
+          step_ns_one=int(round(one['step_ns'])), stream_gbps=int(round(gbps)),
+          measured=dict(full=[small, full['blocks'], full['steps'], full['us']],
+                        one=[small, one['blocks'], one['steps'], one['us']],
+                        stream=[big, stream['blocks'], stream['steps'], stream['us']]))
+      print('%-28s full %6.0f ns/step (%4d wgs)  one %6.0f ns/step (%4d wgs)  stream %5.0f '
+            'GB/s of step_bytes (%4d wgs, %.0f ns/step)' % (
+                k['name'], full['step_ns'], full['blocks'], one['step_ns'], one['blocks'],
+                gbps, stream['blocks'], stream['step_ns']), flush=True)
+  with open(path, 'w') as f:
+    json.dump(table, f, indent=1, sort_keys=True)
+  print('wrote', path)
+
+
+if __name__ == '__main__':
+  if len(sys.argv) > 1 and sys.argv[1] == '--child':
+    child(sys.argv[2], int(sys.argv[3]), None if sys.argv[4] == '-' else sys.argv[4],
+          int(sys.argv[5]), int(sys.argv[6]))
+  else:
+    main()

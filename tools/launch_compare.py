@@ -15,17 +15,21 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
   app, n, iterate, variant = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
   st = frontend.load(os.path.join(ROOT, 'tests', 'samples', app + '.soda'), iterate=iterate)
   spec = specmod.spec_from_stencil(st)
-  opts = {k: (int(v) if v.lstrip('-').isdigit() else v)
+  opts = {k: ([int(x) for x in v.split('/')] if '/' in v else
+              int(v) if v.lstrip('-').isdigit() else v)
           for k, v in (kv.split('=', 1) for kv in variant.split(',') if kv)}
   text, _ = kernel.generate(spec, **opts)
   path = '/tmp/lc_%d.hsaco' % os.getpid()
   kernel.compile_to_code_object(text, path)
   prog = host.open_program(blob=path, spec=spec)
   shape = (n,) * spec['dim']
+  if os.environ.get('LC_WARM'):
+    pass
   a = np.random.default_rng(1).random(shape, dtype=np.float32)
   din = host.DeviceArray(a.nbytes); din.upload(a)
   dout = host.DeviceArray(a.nbytes); dout.zero()
-  t = prog.sweep_timed([din.ptr], [dout.ptr], list(shape), iterate, warmup=2, repeats=3)
+  t = prog.sweep_timed([din.ptr], [dout.ptr], list(shape), iterate,
+                       warmup=int(os.environ.get('LC_WARMUP', '2')), repeats=3)
   print('TOTAL %.1f' % t['kernel_us'])
   sys.exit(0)
 
@@ -46,11 +50,12 @@ for variant in sys.argv[4:]:
   print('%-40s %d launches  sum of fastest %.1f us  sweep %.1f us' % (
       variant, len(launches), sum(l[1] for l in launches), float(total.group(1))))
 if len(runs) > 1 and len({len(r[1]) for r in runs}) == 1:
-  print('%3s  %-18s' % ('#', 'box') + ''.join('  %-26s' % r[0][:26] for r in runs))
+  print('%3s  %-18s' % ('#', 'box') + ''.join('  %-32s' % r[0][:32] for r in runs))
   best_sum = 0.0
   for i in range(len(runs[0][1])):
     cells = [r[1][i] for r in runs]
     best_sum += min(c[1] for c in cells[1:]) if len(cells) > 1 else cells[0][1]
     print('%3d  %-18s' % (i, cells[0][3]) + ''.join(
-        '  %-14s %7.1f us' % (c[0].split('_fused_')[-1], c[1]) for c in cells))
+        '  %-5s %7.1f us (model %6.1f)' % (c[0].split('_fused_')[-1], c[1], c[2])
+        for c in cells))
   print('best single-kernel choice per launch (columns 2..): %.1f us' % best_sum)
