@@ -92,7 +92,7 @@ def build_chain(spec, depth, prefetch):
 def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
          max_period=12, vgpr_budget=250, waves_per_eu=0, xcd_tiles=1, ring=0,
          pairs=0, align_out=16, xcd_runs=1, stamps=0,
-         flat_stores=0):
+         flat_stores=2, skip_fill=0, fence=1):
   """Returns (text, kernel table entry).
 
   `prefetch` = input planes loaded ahead into REGISTERS (R*C VGPRs each);
@@ -133,6 +133,26 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   Measured (jacobi3d 512^3): 343 us against 294 us with the branches - the stamped
   build shows the wavefronts stalled at the ISSUE of the stores (memory back-pressure),
   and the select per row un-fuses the DPP adds; off.
+  `flat_stores` = 2: no branch inside a step at all - the band function is
+  instantiated for ragged and for full tiles (decided once per workgroup), a lane's
+  part of the store predicate is a loop-invariant offset, and a row's or plane's part
+  is the record count of the row's buffer resource (0 drops the store): scalar selects
+  instead of branches, the same eight store instructions every step.
+  `skip_fill` = 1: a stage instance runs only at the steps whose plane some output
+  plane of the chunk depends on, and input planes beyond the chunk's upper halo are
+  not loaded.  A chunk of n planes walks n + fill steps; without this every level
+  computes (and the loader fetches) at all of them - 4 (n + 13) level-planes where
+  4 n + 12 are needed at depth 4, and 5 of 113 input planes per chunk of 100 read
+  for nothing.  Wave-uniform scalar branches; results are untouched (a skipped plane
+  lies outside every dependency cone).  skip_fill = 2: only the loads.  Measured
+  (jacobi3d, one depth-4 launch): 512^3 277 us without, 318 us with; 400^3 139 / 148 -
+  the branches cut the step's one basic block into pieces the scheduler no longer
+  overlaps; off.
+  `fence` = 1: a scheduling fence (`sched_barrier`) between the parts of a step.
+  Without branches (flat_stores = 2) a step is ONE basic block of ~550 instructions
+  and the scheduler's own order was 25 % slower than the same code with fences
+  (348 vs 280 us, found because the STAMPED diagnostic build ran faster than the
+  plain one).
   `stamps` = device address of a debug buffer (tools/blk_stamps.py only): the
   wavefront sums the shader cycles (s_memtime) it spends in each part of a step -
   input plane, each stage instance, the barrier - and lane 0 writes the sums there;
@@ -160,6 +180,18 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     raise NotFusable('ring and register prefetch exclude each other')
   insts, final = build_chain(spec, depth, prefetch)
   source = insts[0]
+  # planes of an instance that the chunk's output planes [z0, z1) depend on:
+  # [z0 - need_lo, z1 + need_hi)
+  for inst in insts:
+    inst.need_lo = inst.need_hi = None
+  final.need_lo = final.need_hi = 0
+  for inst in reversed(insts):
+    if inst.need_lo is None:
+      continue
+    for src, rel, _ in inst.reads:
+      lo_need, hi_need = inst.need_lo - rel[2], inst.need_hi + rel[2]
+      src.need_lo = lo_need if src.need_lo is None else max(src.need_lo, lo_need)
+      src.need_hi = hi_need if src.need_hi is None else max(src.need_hi, hi_need)
   rows_per_load = 16 // (C * elem)     # a 16-byte-per-lane load covers this many rows
   if ring and (rows_per_load < 1 or R % rows_per_load):
     raise NotFusable('ring: %d rows per load do not divide %d rows' % (rows_per_load, R))
@@ -290,6 +322,8 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     for r in range(R):
       line('  ' + ' '.join('v%d_%d = t%d[%d];' % (r, c, r, c) for c in range(C)))
     line('}')
+  if flat_stores == 2:
+    line('template <bool RAGGED>')
   line('DEV void %s_band(const soda_hip_args& a, const i64 xs, const i64 yb, '
        'const i64 wx, const i64 wy, const i64 z0, const i64 z1, const int wave, '
        'const int lane, %s (*edges)[%d][%d][%d][%d], %s (*in_ring)[%d][%d][%d]) {'
@@ -311,8 +345,22 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('  const bool st_full = x >= st_lo && x + %d <= st_hi;' % C)
   for c in range(C):
     line('  const bool st_col%d = x + %d >= st_lo && x + %d < st_hi;' % (c, c, c))
-  line('  const bool st_ragged = __builtin_amdgcn_ballot_w64(!st_full && (%s)) != 0;'
-       % ' || '.join('st_col%d' % c for c in range(C)))
+  if flat_stores == 2:
+    # no branch inside a step: raggedness is a template parameter, the lane's part of
+    # the store predicate a loop-invariant offset, the row's and the plane's part the
+    # record count of the row's buffer resource (scalar selects)
+    line('  const bool st_ragged = RAGGED;')
+    line('  const unsigned st_voff = st_full ? lane_byte : 0xfffffff0u;')
+    for c in range(C):
+      line('  const unsigned st_voff%d = st_col%d ? lane_byte + %d : 0xfffffff0u;'
+           % (c, c, c * elem))
+    line('  unsigned st_rows = 0;')
+    for r in range(R):
+      line('  if (y_band + %d >= st_ylo && y_band + %d < st_yhi) st_rows |= %du;'
+           % (r, r, 1 << r))
+  else:
+    line('  const bool st_ragged = __builtin_amdgcn_ballot_w64(!st_full && (%s)) != 0;'
+         % ' || '.join('st_col%d' % c for c in range(C)))
   line('  const %s* __restrict__ g_in = (const %s*)a.tensor[%d];'
        % (T, T, index[spec['inputs'][0]['name']]))
   line('  %s* __restrict__ g_out = (%s*)a.tensor[%d];' % (T, T, index[out_name]))
@@ -327,6 +375,25 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
                                for c in range(C)))
   line('  i64 head = z0 - %d;' % lo[2])
   line('  const i64 steps = (z1 - z0) + %d;' % (L + lo[2]))
+  line('  const i64 span = z1 - z0;')
+
+  def active(inst, u):
+    """Condition (wave-uniform) under which `inst` has to run at unrolled step u:
+    its plane head + u - lag - ready... lies inside [z0 - need_lo, z1 + need_hi)."""
+    if not skip_fill or ring or inst.need_lo is None:
+      return None
+    if skip_fill == 2 and inst.stage is not None:     # loads only
+      return None
+    if skip_fill == 3:      # loads only, without a branch (out-of-range offsets)
+      return None
+    # the plane handled at step s = n + u is z0 - lo[2] + s - lag
+    first = lo[2] + inst.lag - inst.need_lo
+    last = lo[2] + inst.lag + inst.need_hi          # s < span + last
+    parts = []
+    if first > 0:
+      parts.append('n + %d >= %d' % (u, first))
+    parts.append('n + %d < span + %d' % (u, last))
+    return ' && '.join(parts)
 
   def ring_load(slot_index, plane_expr, indent):
     line(indent + '{ i64 zz = %s; if (zz > D - 1) zz = D - 1;' % plane_expr)
@@ -356,6 +423,10 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     line('  unsigned long long soda_prev = __builtin_readcyclecounter();')
 
   def stamp(k):
+    if fence and not stamps:
+      # scheduling fence between the parts of a step: the input plane, each stage
+      # instance, the barrier (what the stamped diagnostic build has as well)
+      line('      __builtin_amdgcn_sched_barrier(0);')
     if stamps:
       line('      __builtin_amdgcn_sched_barrier(0);')
       line('      { const unsigned long long now = __builtin_readcyclecounter(); '
@@ -435,13 +506,21 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
         continue
       if inst.stage is None:
         s = slot(inst, u, 0)
-        line('      { i64 zz = head + %d; if (zz > D - 1) zz = D - 1;' % u)
+        cond = active(inst, u)
+        oob = skip_fill == 3 and not ring
+        if oob:      # no branch: planes nobody needs are "loaded" out of range
+          cond = None
+          line('      const unsigned ld_byte_%d = n + %d < span + %d ? lane_byte : '
+               '0xfffffff0u;' % (u, u, lo[2] + inst.lag + inst.need_hi))
+        line('      %s{ i64 zz = head + %d; if (zz > D - 1) zz = D - 1;' % (
+            'if (%s) ' % cond if cond else '', u))
         line('        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
              'rsrc((void*)(g_in + zz * plane), 0, (int)plane_bytes, 0x27000);')
         for r in range(R):
           line('        { const %s v = __builtin_bit_cast(%s, __builtin_amdgcn_raw_'
-               'buffer_load_%s(rs, lane_byte, (unsigned)(%d * W * %d), 0));%s }' % (
-                   vec, vec, suffix, r, elem, ''.join(
+               'buffer_load_%s(rs, %s, (unsigned)(%d * W * %d), 0));%s }' % (
+                   vec, vec, suffix, 'ld_byte_%d' % u if oob else 'lane_byte', r, elem,
+                   ''.join(
                        ' %s = v[%d];' % (cell(inst.ident, s, r, c), c)
                        for c in range(C))))
         line('      }')
@@ -451,7 +530,8 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
       stage = inst.stage
       ctype = builtin_type(inst.c_type)
       by_name = {(n, rel): src for src, rel, n in inst.reads}
-      line('      {')
+      cond = active(inst, u)
+      line('      %s{' % ('if (%s) ' % cond if cond else ''))
       # rows of the neighbouring bands this stage reads
       wanted = {}
       for src, rel, _ in inst.reads:
@@ -487,7 +567,25 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
           cell_assignment(stage, target, load, line, '        ')
       if inst.up or inst.down:
         publish(inst, u, slot(inst, u, 0))
-      if inst.final and (ring or flat_stores):
+      if inst.final and flat_stores == 2 and not ring:
+        line('        const i64 z = head + %d;' % (u - L))
+        line('        const bool z_ok = z >= z0 && z < z1;')
+        line('        const unsigned rows_now = z_ok ? st_rows : 0u;')
+        line('        %s* const out_plane = g_out + (z_ok ? z : z0) * plane;' % T)
+        for r in range(R):
+          line('        { const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
+               'rsrc((void*)out_plane, 0, (rows_now >> %d) & 1u ? (int)plane_bytes : 0, '
+               '0x27000);' % r)
+          line('          if (!RAGGED) { %s v;%s __builtin_amdgcn_raw_buffer_store_%s('
+               '__builtin_bit_cast(%s, v), rs, st_voff, (unsigned)(%d * W * %d), 0); }' % (
+                   vec, ''.join(' v[%d] = %s;' % (c, out_cell(r, c))
+                                for c in range(C)), suffix, buf_type, r, elem))
+          line('          else {%s }' % ''.join(
+              ' __builtin_amdgcn_raw_buffer_store_b32(%s_bits(%s), rs, st_voff%d, '
+              '(unsigned)(%d * W * %d), 0);' % (name, out_cell(r, c), c, r, elem)
+              for c in range(C)))
+          line('        }')
+      elif inst.final and (ring or flat_stores):
         # the same number of stores every step (the counted wait above): a plane
         # or row that is not to be stored gets out-of-range offsets
         line('        const i64 z = head + %d;' % (u - L))
@@ -593,8 +691,24 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('  i64 wy = yb;')
   line('  if (wy + %d > a.dims[1]) wy = a.dims[1] - %d;' % (TR, TR))
   line('  if (wy < 0) wy = 0;')
-  line('  %s_band(a, xs, yb, wx, wy, z0, z1, wave, lane, edges, %s);'
-       % (name, 'in_ring' if ring else 'nullptr'))
+  if flat_stores == 2:
+    # does any lane of this tile store only some of its columns?  (tiles at the box's
+    # x edges when the box does not start or end on a lane boundary)
+    line('  const i64 x = wx + lane * %d;' % C)
+    line('  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];')
+    line('  const i64 st_hi = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];'
+         % (w_out, w_out))
+    line('  const bool partial = !(x >= st_lo && x + %d <= st_hi) && (%s);' % (
+        C, ' || '.join('(x + %d >= st_lo && x + %d < st_hi)' % (c, c) for c in range(C))))
+    line('  if (__builtin_amdgcn_ballot_w64(partial) != 0)')
+    line('    %s_band<true>(a, xs, yb, wx, wy, z0, z1, wave, lane, edges, %s);'
+         % (name, 'in_ring' if ring else 'nullptr'))
+    line('  else')
+    line('    %s_band<false>(a, xs, yb, wx, wy, z0, z1, wave, lane, edges, %s);'
+         % (name, 'in_ring' if ring else 'nullptr'))
+  else:
+    line('  %s_band(a, xs, yb, wx, wy, z0, z1, wave, lane, edges, %s);'
+         % (name, 'in_ring' if ring else 'nullptr'))
   line('}')
   entry = dict(name=name, kind='fused', depth=depth, stage=-1,
                block=[G * LANES, 1, 1], tile=[w_out, r_out, chunk_planes, 1],
@@ -602,5 +716,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
                prefetch=prefetch, period=period, est_vgprs=est_vgprs, w_out=w_out,
                r_out=r_out, lds_bytes=lds_bytes + ring_bytes, ring=ring, pairs=pairs,
                xcd_tiles=(-1 if xcd_runs else 1) if xcd_tiles else 0,
+               skip_fill=int(bool(skip_fill and not ring)), fence=int(bool(fence)),
+               flat_stores=int(flat_stores),
                min_extent=[LANES * C, TR])
   return '\n'.join(o) + '\n', entry
