@@ -5,7 +5,7 @@
 # --pmc FETCH_SIZE and one --pmc WRITE_SIZE pass (separate runs: the TCC block
 # cannot count both at once, MI355X_MICROARCH.md, rocprofv3 PMC slots).
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out
 rm -rf $out/prof_$tag $out/pmc_${tag}_*
@@ -21,6 +21,8 @@ cfg5|--app jacobi3d --size 512 512 512 --iterate 200
 seidel2d|--app seidel2d --size 16384 16384 --iterate 100
 sobel2d|--app sobel2d --size 16384 16384 --iterate 1
 heat3d|--app heat3d --size 512 512 512 --iterate 20
+denoise2d|--app denoise2d --size 8192 8192 --iterate 1
+denoise3d|--app denoise3d --size 256 256 256 --iterate 1
 WL
 while IFS='|' read -r name wargs; do
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -29,4 +31,10 @@ while IFS='|' read -r name wargs; do
         > $out/pmc_${tag}_${name}_$c.log 2>&1
   done
   echo "pmc $name done"
+done < $out/pmc_${tag}_workloads.txt
+# SQ counters (VALU issue utilisation, where a wavefront spends its life): three more
+# --pmc passes per workload (tools/sq_counters.sh), summarised per kernel
+while IFS='|' read -r name wargs; do
+  bash tools/sq_counters.sh ${tag}_${name} $wargs > /dev/null 2>&1 || echo "sq $name FAILED"
+  echo "sq $name done"
 done < $out/pmc_${tag}_workloads.txt

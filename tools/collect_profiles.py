@@ -5,6 +5,8 @@ tools/collect_on_gpu.sh) into the small files committed under profiles/:
   <round>_kernel_stats.csv          --kernel-trace --stats summary of bench.py
   <round>_bench_under_rocprof.json  the bench line printed during that pass
   <round>_traffic.json              HBM bytes per launch from the PMC passes
+  <round>_sq_counters.json          SQ counters per kernel (tools/sq_counters.sh): VALU
+                                    issue utilisation, wavefront time shares
 
 The traffic file holds one entry per (kernel, grid, iteration count): a figure
 measured on one grid says nothing about another, so bench.py only quotes an entry
@@ -84,6 +86,40 @@ def main():
           correction='FETCH_SIZE x2 (gfx950), WRITE_SIZE x1', commit=commit))
   with open(os.path.join(dst, '%s_traffic.json' % tag), 'w') as f:
     json.dump(dict(entries=entries), f, indent=1, sort_keys=True)
+  sq_entries = []
+  for name, args in workloads:
+    path = os.path.join(src, 'sq_%s_%s' % (tag, name), 'summary.json')
+    if not os.path.exists(path):
+      continue
+    words = args.split()
+    i = words.index('--size') + 1
+    dims = []
+    while i < len(words) and not words[i].startswith('--'):
+      dims.append(int(words[i]))
+      i += 1
+    iterate = int(words[words.index('--iterate') + 1])
+    with open(path) as f:
+      summary = json.load(f)
+    for kernel, counters in sorted(summary.items()):
+      derived = counters.get('_derived')
+      if not derived or '_fused_' not in kernel and '_stage_' not in kernel:
+        continue
+      sq_entries.append(dict(
+          workload=name, kernel=kernel, dims=dims, iterate=iterate, commit=commit,
+          launches=counters.get('_launches'),
+          valu_instructions=counters.get('SQ_INSTS_VALU'),
+          **{k: derived[k] for k in ('valu_issue_utilisation', 'valu_cycles_per_instruction',
+                                     'wave_issuing', 'wave_issue_stalled', 'wave_parked',
+                                     'lds_busy', 'lds_conflict_share', 'shader_cycles')}))
+  if sq_entries:
+    with open(os.path.join(dst, '%s_sq_counters.json' % tag), 'w') as f:
+      json.dump(dict(entries=sq_entries,
+                     note='per-launch averages of rocprofv3 --pmc passes (tools/sq_counters.sh); '
+                          'wave_* = shares of SQ_WAVE_CYCLES'), f, indent=1, sort_keys=True)
+    for e in sq_entries:
+      print('%-10s %-28s VALU busy %.2f  issuing %.2f  issue-stalled %.2f  parked %.2f' % (
+          e['workload'], e['kernel'], e['valu_issue_utilisation'], e['wave_issuing'],
+          e['wave_issue_stalled'], e['wave_parked']))
   p = os.path.join(src, 'prof_%s_bench.log' % tag)
   if os.path.exists(p):
     with open(p) as f:
