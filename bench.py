@@ -59,6 +59,10 @@ def parse_args():
                   help='N > 1: exchange on a side stream beside the interior '
                        'sweep (boundary bands first); default is exchange, then '
                        'sweep')
+  ap.add_argument('--no-tune', action='store_true',
+                  help='split `iterate` into fused depths by the calibrated model alone '
+                       'instead of timing the candidate splits on this grid during '
+                       'warm-up (soda_hip_plan_tune)')
   ap.add_argument('--jit', action='store_true',
                   help='compile the kernels with hiprtc instead of loading the '
                        'code object built by __graft_entry__.build()')
@@ -305,6 +309,12 @@ def run_single(args):
   for _ in range(args.warmup):
     program.sweep(ip, op, dims, args.iterate)
   sync()
+  if not args.no_tune and args.iterate > 1:
+    # untimed, like the warm-up: the candidate splits of `iterate` run as whole
+    # sweeps, the fastest on this device is kept
+    program.tune(ip, op, dims, args.iterate)
+    program.sweep(ip, op, dims, args.iterate)
+    sync()
   t0 = time.perf_counter()
   for _ in range(args.steps):
     program.sweep(ip, op, dims, args.iterate)
@@ -333,6 +343,8 @@ def run_single(args):
                   nominal_gcell_updates_per_s=nominal / (wall / args.steps) / 1e9,
                   launches_per_step=timing['launches'],
                   depth_schedule=schedule_text(schedule),
+                  depth_split='measured (soda_hip_plan_tune)' if not args.no_tune and
+                  args.iterate > 1 else 'calibrated model',
                   effective_GBps=valid * abytes / (wall / args.steps) / 1e9,
                   device=host.device_info(0)['arch']),
       roofline=roofline_block(spec, program, schedule,

@@ -274,6 +274,19 @@ int soda_hip_plan_schedule(soda_hip_plan* plan,
  * tuning. */
 int soda_hip_plan_set_max_depth(soda_hip_plan* plan, int max_depth);
 
+/* Optional: finds the split of `iterate` into fused depths that runs fastest on THIS
+ * device for arrays of these extents.  The scheduler's model ranks depths within a few
+ * percent of each other; this takes its split and the ones it gives when each deep
+ * kernel in turn is priced 12 % lower or higher, runs every distinct candidate as a
+ * whole sweep (in -> out, as soda_hip_sweep; one untimed run, then the faster of two)
+ * and remembers the fastest: later sweeps and schedules with the same dims and
+ * `iterate` use it.  A split can only change speed, never results.  Synchronous; a
+ * few sweeps' worth of time (the untimed warm-up run of the reference protocol,
+ * host.py:775-790, is the natural place for it). */
+int soda_hip_plan_tune(soda_hip_plan* plan, void* const* in, void* const* out,
+                       const int64_t dims[SODA_HIP_MAX_DIMS], int iterate,
+                       const int32_t* valid_lo, const int32_t* valid_hi, void* stream);
+
 /* on != 0: a sweep writes `out` with its LAST launch only; the launches before it
  * alternate between two plan-owned arrays (the second one is allocated when a sweep
  * first needs it).  By default the intermediate launches alternate between one

@@ -100,6 +100,16 @@ struct soda_hip_plan {
   // XCD super-tile shape chosen per (kernel, tiles along x, y, chunks): the search
   // walks every super-tile and a sweep's launches mostly repeat a few grids
   mutable std::map<std::array<int64_t, 4>, std::pair<int, int>> xcd_shape;
+  // soda_hip_plan_tune: the split of `iterate` (fused depths, deepest first) that ran
+  // fastest on this device for arrays of these extents, keyed by dims + iterate (the
+  // margins of a resumed or sharded run move the boxes by a few cells, not the
+  // ranking); where an entry exists build_schedule uses it instead of its own split
+  std::map<std::array<int64_t, 5>, std::vector<int>> tuned_split;
+  // while tuning: the modelled price of kernels of this depth is scaled by this
+  // factor (how the candidate splits are generated); 0 = no bias
+  int bias_depth = 0;
+  double bias = 1.0;
+  bool tuning = false;               // candidates are being timed: ignore tuned_split
 };
 
 namespace {
@@ -579,13 +589,30 @@ int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
       bool empty = false;
       int rc = make_launch(plan, k, first_box(k), &l, &empty);
       if (rc) return rc;
+      if (plan->bias_depth == plan->kernels[k].depth) l.est_us *= plan->bias;
       if (!empty && l.est_us <= 0) priced = false;
       usable.push_back(k);
       price.push_back(empty ? kModelLaunchUs : l.est_us);
     }
     if (usable.empty()) return fail(SODA_HIP_ERR_INTERNAL, "no fused kernel of depth 1");
     std::vector<int> seq;
-    if (priced) {
+    std::array<int64_t, 5> tune_key;
+    for (int d = 0; d < 4; ++d) tune_key[d] = d < p.dim ? dims[d] : 1;
+    tune_key[4] = iterate;
+    const auto tuned = plan->tuned_split.find(tune_key);
+    if (!plan->tuning && tuned != plan->tuned_split.end()) {
+      // the split that ran fastest here (soda_hip_plan_tune): depth -> the first
+      // usable kernel of that depth (same-depth alternatives are chosen per launch
+      // below, as always)
+      for (int depth : tuned->second)
+        for (int k : usable)
+          if (plan->kernels[k].depth == depth) { seq.push_back(k); break; }
+      int total = 0;
+      for (int k : seq) total += plan->kernels[k].depth;
+      if (total != iterate) seq.clear();     // kernels changed since: fall back
+    }
+    if (!seq.empty()) {
+    } else if (priced) {
       std::vector<double> best(iterate + 1, 1e300);
       std::vector<int> pick(iterate + 1, -1);
       best[0] = 0;
@@ -1062,6 +1089,80 @@ int soda_hip_plan_set_max_depth(soda_hip_plan* plan, int max_depth) {
   if (!plan) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "plan is NULL");
   plan->max_depth = max_depth;
   return 0;
+}
+
+int soda_hip_plan_tune(soda_hip_plan* plan, void* const* in, void* const* out,
+                       const int64_t dims[SODA_HIP_MAX_DIMS], int iterate,
+                       const int32_t* valid_lo, const int32_t* valid_hi, void* stream) {
+  if (!plan || !in || !out || !dims) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  const soda_hip_program& p = plan->prog;
+  hipStream_t s = as_stream(stream);
+  std::array<int64_t, 5> key;
+  for (int d = 0; d < 4; ++d) key[d] = d < p.dim ? dims[d] : 1;
+  key[4] = iterate;
+  // candidate splits: the scheduler's own, and its answer when every deep kernel in
+  // turn is made 12 % cheaper or dearer (the model ranks depths within a few percent
+  // of each other; what really runs fastest depends on the device and the grid)
+  std::vector<int> depths;
+  for (const soda_hip_kernel& kd : plan->kernels)
+    if (kd.kind == SODA_HIP_KERNEL_FUSED && kd.depth >= 4 && kd.depth <= iterate &&
+        std::find(depths.begin(), depths.end(), kd.depth) == depths.end())
+      depths.push_back(kd.depth);
+  std::vector<std::vector<int>> candidates;
+  plan->tuning = true;
+  int rc = 0;
+  for (int i = -1; i < 2 * (int)depths.size() && !rc; ++i) {
+    plan->bias_depth = i < 0 ? 0 : depths[i / 2];
+    plan->bias = i % 2 == 0 ? 0.88 : 1.12;
+    std::vector<Launch> list;
+    int depth = 0;
+    rc = build_schedule(plan, nullptr, nullptr, dims, iterate, valid_lo, valid_hi, &list,
+                        &depth, nullptr, true);
+    std::vector<int> split;
+    for (const Launch& l : list)
+      if (plan->kernels[l.kernel].kind == SODA_HIP_KERNEL_FUSED)
+        split.push_back(plan->kernels[l.kernel].depth);
+    int total = 0;
+    for (int d : split) total += d;
+    if (!rc && total == iterate &&
+        std::find(candidates.begin(), candidates.end(), split) == candidates.end())
+      candidates.push_back(split);
+  }
+  plan->bias_depth = 0;
+  plan->bias = 1.0;
+  plan->tuning = false;
+  if (rc || candidates.size() < 2) return rc;     // nothing to choose from
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+    return fail(SODA_HIP_ERR_DEVICE_RUN, "hipEventCreate failed");
+  // every candidate as a whole sweep, in context: one untimed run, then the faster
+  // of two timed ones
+  size_t best = 0;
+  float best_ms = 0;
+  for (size_t c = 0; c < candidates.size() && !rc; ++c) {
+    plan->tuned_split[key] = candidates[c];
+    float fastest = 0;
+    for (int run = 0; run < 3 && !rc; ++run) {
+      if (hipEventRecord(e0, s) != hipSuccess) rc = fail(SODA_HIP_ERR_DEVICE_RUN, "hipEventRecord failed");
+      if (!rc) rc = soda_hip_sweep(plan, in, out, dims, iterate, valid_lo, valid_hi, stream);
+      if (!rc && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess))
+        rc = fail(SODA_HIP_ERR_DEVICE_SYNC, "timing a tuning sweep failed");
+      float ms = 0;
+      if (!rc) (void)hipEventElapsedTime(&ms, e0, e1);
+      if (run == 1 || (run == 2 && ms < fastest)) fastest = ms;
+    }
+    if (tuning_env("SODA_HIP_DEBUG")) {
+      fprintf(stderr, "soda_hip: tune %d iteration(s):", iterate);
+      for (int d : candidates[c]) fprintf(stderr, " %d", d);
+      fprintf(stderr, "  -> %.1f us\n", fastest * 1000.0);
+    }
+    if (c == 0 || fastest < best_ms) { best = c; best_ms = fastest; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc) plan->tuned_split.erase(key);
+  else plan->tuned_split[key] = candidates[best];
+  return rc;
 }
 
 int soda_hip_plan_set_out_final_only(soda_hip_plan* plan, int on) {

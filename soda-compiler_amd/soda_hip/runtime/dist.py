@@ -413,6 +413,14 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
     exchange_ghosts(a, plan, dist)
     for _ in range(args.warmup):
       step()
+    if not getattr(args, 'no_tune', False) and args.iterate > 1:
+      # untimed: the candidate splits of a super-step on this rank's slab
+      # (soda_hip_plan_tune; no communication inside)
+      torch.cuda.synchronize()
+      program.tune([a.data_ptr()], [b.data_ptr()], plan.local_dims,
+                   min(plan.exchange, args.iterate),
+                   stream=torch.cuda.current_stream().cuda_stream)
+      step()
     torch.cuda.synchronize()
     order.exchange_ms()
     dist.barrier()

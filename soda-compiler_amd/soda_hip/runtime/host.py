@@ -267,6 +267,19 @@ class Program:
         self.handle, self._ptr_array(in_ptrs), self._ptr_array(out_ptrs),
         self._dims(dims), iterate, vlo, vhi, stream))
 
+  def tune(self, in_ptrs, out_ptrs, dims, iterate, valid_lo=None, valid_hi=None,
+           stream=None):
+    """Runs the candidate splits of `iterate` as whole sweeps and keeps the fastest
+    for later sweeps of the same extents (soda_hip_plan_tune)."""
+    vlo = vhi = None
+    if valid_lo is not None:
+      vlo = (ctypes.c_int32 * 4)(*(list(valid_lo) + [0] * (4 - len(valid_lo))))
+    if valid_hi is not None:
+      vhi = (ctypes.c_int32 * 4)(*(list(valid_hi) + [0] * (4 - len(valid_hi))))
+    capi.check(capi.lib().soda_hip_plan_tune(
+        self.handle, self._ptr_array(in_ptrs), self._ptr_array(out_ptrs),
+        self._dims(dims), iterate, vlo, vhi, stream))
+
   def schedule(self, dims, iterate, valid_lo=None, valid_hi=None):
     """The launches `sweep` would issue: [(kernel table entry, modelled us)]."""
     vlo = vhi = None

@@ -1021,6 +1021,40 @@ def test_multi_process_slabs_on_one_gpu(tmp_path, app, dims, world, iterate, exc
   assert min(n_exchanges) >= -(-iterate // exchange)
 
 
+@pytest.mark.parametrize('app,shape,iterate', [
+    ('jacobi2d', (700, 1300), 50), ('seidel2d', (500, 1100), 30),
+    ('jacobi3d', (150, 140, 130), 10)])
+def test_tuned_split_changes_speed_only(app, shape, iterate):
+  """soda_hip_plan_tune runs the candidate splits of `iterate` as whole sweeps and
+  keeps the fastest for these extents: the schedule afterwards still adds up to
+  `iterate`, the result is still the oracle's, and other extents are unaffected."""
+  spec = gpu_util.load_spec(app)
+  prog = gpu_util.open_prebuilt(app)      # a plan of its own: tuning is plan state
+  try:
+    (a,) = gpu_util.random_inputs(spec, shape)
+    dims = list(reversed(shape))
+    din, dout = host.DeviceArray(a.nbytes), host.DeviceArray(a.nbytes)
+    din.upload(a)
+    dout.zero()
+    before = [k['depth'] for k, _ in prog.schedule(dims, iterate)]
+    prog.tune([din.ptr], [dout.ptr], dims, iterate)
+    after = [k['depth'] for k, _ in prog.schedule(dims, iterate)]
+    assert sum(after) == iterate == sum(before)
+    assert after == sorted(after, reverse=True)
+    other = [k['depth'] for k, _ in prog.schedule([d + 8 for d in dims], iterate)]
+    assert sum(other) == iterate
+    prog.sweep([din.ptr], [dout.ptr], dims, iterate)
+    got = dout.download(a.shape, a.dtype)
+    orc = oracle(app)
+    want = orc.run([a], iterate=iterate)[spec['outputs'][0]]
+    sl = orc.valid_slices(tuple(dims), iterate)
+    assert want[sl].size > 0 and np.array_equal(got[sl], want[sl])
+    din.free()
+    dout.free()
+  finally:
+    prog.close()
+
+
 def build_rccl_standin(tmp_path):
   """tests/rccl_standin: ncclSend / ncclRecv / groups for ranks that are threads of
   one process on one GPU (a TEST library; soname librccl.so so that libsoda_hip's
@@ -1102,7 +1136,7 @@ def test_bench_py_as_the_driver_launches_it_for_two_gpus():
       [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
        '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
        os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-       '--size', '4096', '3000', '--iterate', '120'],
+       '--size', '4096', '3000', '--iterate', '120', '--cpu-seconds', '2'],
       capture_output=True, text=True, timeout=600,
       env=dict(os.environ, SODA_DIST_BACKEND='gloo', OMP_NUM_THREADS='2'))
   assert r.returncode == 0, r.stderr[-2000:]
@@ -1125,7 +1159,11 @@ def test_bench_py_as_the_driver_launches_it_for_two_gpus():
   assert abs(d['value'] - valid / (d['ms_per_step'] * 1e-3) / 1e9) < 1e-6 * d['value']
   rf = d['roofline']
   assert rf['kernel'].startswith('jacobi2d_fused_k') and 0 < rf['frac'] < 1.5
-  assert 'cpu_baseline' not in d        # rank 0 at N = 1 only
+  # the CPU figure stands beside every point of the curve: rank 0 times
+  # the oracle port on the whole grid AFTER the timed region, the others wait
+  cpu = d['cpu_baseline']
+  assert cpu['kind'] == 'port' and cpu['value'] > 0 and len(cpu['samples']) == 3
+  assert c['super_step_schedule']
 
 
 def test_denormals_signed_zeros_and_infinities():
