@@ -37,6 +37,7 @@ between neighbouring PEs are the published edge rows.
 Scope: one input, one output, 4-byte elements, x offsets within C columns,
 y offsets within R rows.
 """
+from . import kernel_asm
 from . import spec as specmod
 from .kernel_common import builtin_type, cell_assignment, device_expr, tensor_index
 from .kernel_stream2d import LANES, Instance, NotFusable
@@ -92,7 +93,8 @@ def build_chain(spec, depth, prefetch):
 def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
          max_period=12, vgpr_budget=250, waves_per_eu=0, xcd_tiles=1, ring=0,
          pairs=0, align_out=16, xcd_runs=1, stamps=0,
-         flat_stores=2, skip_fill=0, fence=1):
+         flat_stores=2, skip_fill=0, fence=1, asm_sched=0, asm_group=4,
+         edge_ahead=1):
   """Returns (text, kernel table entry).
 
   `prefetch` = input planes loaded ahead into REGISTERS (R*C VGPRs each);
@@ -148,6 +150,18 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   (jacobi3d, one depth-4 launch): 512^3 277 us without, 318 us with; 400^3 139 / 148 -
   the branches cut the step's one basic block into pieces the scheduler no longer
   overlaps; off.
+  `asm_sched` = 1 (plain float programs without division, scalar form): the cells of
+  a level's plane as one interleaved stream of VALU instructions, `asm_group` cells in
+  lock step (kernel_asm.py), instead of C++ statements the scheduler serialises.
+  Bit-exact; measured per 512^3 launch: heat3d (13 operations per cell) 454 -> 386 us,
+  no better than its packed wave-pipelined kernel (380); jacobi3d (7) 257 -> 270: a
+  level's ~112 instructions already issue at the single-wavefront rate (one per ~4.3
+  cycles: tools/blk_stamps.py), the separate DPP moves only add to them.  Off.
+  `edge_ahead` = 1: a level's reads of its neighbours' edge rows (LDS) are issued one
+  part of the step earlier - in front of the previous level's arithmetic (what they
+  read was published before the step's barrier) - so that the round trip runs beside
+  that arithmetic instead of in front of the level's own (with fences the compiler
+  cannot move them there itself); 2: all of them at the start of the step.
   `fence` = 1: a scheduling fence (`sched_barrier`) between the parts of a step.
   Without branches (flat_stores = 2) a step is ONE basic block of ~550 instructions
   and the scheduler's own order was 25 % slower than the same code with fences
@@ -481,8 +495,42 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
       return 'from_lane_below(%s[%d])' % (row, C + j)
     return 'from_lane_above(%s[%d])' % (row, j - C)
 
+  def edge_read_lines(inst, u):
+    """The rows of the neighbouring bands a stage instance reads at step u: loads
+    from the published edge rows (LDS) into registers."""
+    out = []
+    wanted = {}
+    for src, rel, _ in inst.reads:
+      if not rel[1]:
+        continue
+      back = inst.lag - src.lag - rel[2]
+      key = (src.ident, slot(src, u, back))
+      age = inst.lag - rel[2] - src.lag - src.ready
+      wanted[key] = (src, age)
+    for (ident, s), (src, age) in sorted(wanted.items()):
+      for k in range(src.down):     # last rows of the band above
+        out.append('        const %s xa_v_%s_%d_%d = *(const %s*)&%s[lane * %d];' % (
+            vec, ident, s, k, vec, edge(src, u - age, 'wave', src.up + k), C))
+        out.append('        const %s xa_%s_%d_%d[%d] = {%s};' % (
+            builtin_type(src.c_type), ident, s, k, C, ', '.join(
+                'xa_v_%s_%d_%d[%d]' % (ident, s, k, c) for c in range(C))))
+      for k in range(src.up):       # first rows of the band below
+        out.append('        const %s xb_v_%s_%d_%d = *(const %s*)&%s[lane * %d];' % (
+            vec, ident, s, k, vec, edge(src, u - age, 'wave + 2', k), C))
+        out.append('        const %s xb_%s_%d_%d[%d] = {%s};' % (
+            builtin_type(src.c_type), ident, s, k, C, ', '.join(
+                'xb_v_%s_%d_%d[%d]' % (ident, s, k, c) for c in range(C))))
+    return out
+
   for u in range(period):
     line('    {  // unrolled step %d' % u)
+    edges_done = set()
+    if edge_ahead and not ring:
+      ahead = [i for i in insts if i.stage is not None]
+      for inst in (ahead if edge_ahead == 2 else ahead[:1]):
+        edges_done.add(id(inst))
+        for text in edge_read_lines(inst, u):
+          line(text)
     for inst_index, inst in enumerate(insts):
       if inst_index:
         stamp(inst_index - 1)
@@ -531,40 +579,36 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
       ctype = builtin_type(inst.c_type)
       by_name = {(n, rel): src for src, rel, n in inst.reads}
       cond = active(inst, u)
+      if edge_ahead == 1 and not ring:      # the next level's rows, ahead of this one's
+        later = [i for i in insts[insts.index(inst) + 1:] if i.stage is not None]
+        if later:                           # (step scope: the next block uses them)
+          edges_done.add(id(later[0]))
+          for text in edge_read_lines(later[0], u):
+            line(text)
       line('      %s{' % ('if (%s) ' % cond if cond else ''))
-      # rows of the neighbouring bands this stage reads
-      wanted = {}
-      for src, rel, _ in inst.reads:
-        if not rel[1]:
-          continue
-        back = inst.lag - src.lag - rel[2]
-        key = (src.ident, slot(src, u, back))
-        age = inst.lag - rel[2] - src.lag - src.ready
-        wanted[key] = (src, age)
-      for (ident, s), (src, age) in sorted(wanted.items()):
-        for k in range(src.down):     # last rows of the band above
-          line('        const %s xa_v_%s_%d_%d = *(const %s*)&%s[lane * %d];' % (
-              vec, ident, s, k, vec, edge(src, u - age, 'wave', src.up + k), C))
-          line('        const %s xa_%s_%d_%d[%d] = {%s};' % (
-              builtin_type(src.c_type), ident, s, k, C, ', '.join(
-                  'xa_v_%s_%d_%d[%d]' % (ident, s, k, c) for c in range(C))))
-        for k in range(src.up):       # first rows of the band below
-          line('        const %s xb_v_%s_%d_%d = *(const %s*)&%s[lane * %d];' % (
-              vec, ident, s, k, vec, edge(src, u - age, 'wave + 2', k), C))
-          line('        const %s xb_%s_%d_%d[%d] = {%s};' % (
-              builtin_type(src.c_type), ident, s, k, C, ', '.join(
-                  'xb_v_%s_%d_%d[%d]' % (ident, s, k, c) for c in range(C))))
+      if id(inst) not in edges_done:
+        for text in edge_read_lines(inst, u):
+          line(text)
       if pairs:
         ctype = 'pk2'
       if inst.final:
         line('        %s out_tile[%d][%d];' % (ctype, RP, C))
+      by_hand = asm_sched and not pairs and packable(spec) and \
+          kernel_asm.supported(stage)
+      cells = []
       for r in range(RP):
         for c in range(C):
           def load(tensor, rel, u=u, r=r, c=c, inst=inst, by_name=by_name):
             return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, r, c)
           target = ('out_tile[%d][%d]' % (r, c)) if inst.final else \
               '%s[%d][%d][%d]' % (inst.ident, slot(inst, u, 0), r, c)
-          cell_assignment(stage, target, load, line, '        ')
+          if by_hand:
+            cells.append((target, load))
+          else:
+            cell_assignment(stage, target, load, line, '        ')
+      if by_hand:
+        kernel_asm.emit_cells(stage, cells, line, '        ', group=asm_group,
+                              prefix='a%d_%d' % (u, insts.index(inst)))
       if inst.up or inst.down:
         publish(inst, u, slot(inst, u, 0))
       if inst.final and flat_stores == 2 and not ring:
@@ -717,6 +761,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
                r_out=r_out, lds_bytes=lds_bytes + ring_bytes, ring=ring, pairs=pairs,
                xcd_tiles=(-1 if xcd_runs else 1) if xcd_tiles else 0,
                skip_fill=int(bool(skip_fill and not ring)), fence=int(bool(fence)),
+               asm_sched=int(bool(asm_sched and not pairs)),
                flat_stores=int(flat_stores),
                min_extent=[LANES * C, TR])
   return '\n'.join(o) + '\n', entry

@@ -273,7 +273,19 @@ def test_3d_wave_pipelined_forms_on_heat3d(options):
     ('jacobi3d', dict(deep3d='blk', blk_pairs=1)),
     ('jacobi3d', dict(deep3d='blk', blk_prefetch=0, blk_ring=2)),
     ('heat3d', dict(deep3d='blk', blk_stack=4, blk_prefetch=0, blk_pairs=1, blk_ring=2)),
-    ('heat3d', dict(deep3d='blk', blk_stack=4))])
+    ('heat3d', dict(deep3d='blk', blk_stack=4)),
+    # round 3: the shipped form has no branch inside a step (flat_stores=2), scheduling
+    # fences and the next level's edge rows read ahead; the older store paths, the
+    # hand-ordered arithmetic (kernel_asm), the fill-skipping variants and unaligned
+    # tiles in plain order stay correct
+    ('jacobi3d', dict(deep3d='blk', blk_flat_stores=0, blk_fence=0, blk_edge_ahead=0)),
+    ('jacobi3d', dict(deep3d='blk', blk_flat_stores=1, blk_edge_ahead=2)),
+    ('jacobi3d', dict(deep3d='blk', blk_asm_sched=1)),
+    ('heat3d', dict(deep3d='blk', blk_asm_sched=1, blk_asm_group=8)),
+    ('jacobi3d', dict(deep3d='blk', blk_skip_fill=1, blk_flat_stores=0)),
+    ('heat3d', dict(deep3d='blk', blk_skip_fill=3)),
+    ('jacobi3d', dict(deep3d='blk', blk_align_out=2, blk_xcd_runs=0)),
+    ('jacobi3d', dict(deep3d='blk', blk_align_out=32))])
 def test_3d_block_form(app, options):
   """The block form of the depth-4 3-D kernel (kernel_stream3d_blk: all levels in
   every wavefront, bands of rows per wavefront, edge rows through LDS, tiles
