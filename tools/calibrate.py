@@ -145,6 +145,17 @@ def main():
             'GB/s of step_bytes (%4d wgs, %.0f ns/step)' % (
                 k['name'], full['step_ns'], full['blocks'], one['step_ns'], one['blocks'],
                 gbps, stream['blocks'], stream['step_ns']), flush=True)
+  # entries of the calibrated apps whose kernel shape no longer exists are stale
+  live = set()
+  for app in apps:
+    st = frontend.load(entry.sample_path(app), iterate=entry.BLOB_ITERATE.get(app))
+    spec = specmod.spec_from_stencil(st)
+    for k in kernel.generate(spec)[1]:
+      if k['kind'] == 'fused':
+        live.add(kernel.calibration_key(k, specmod.inline_pointwise(spec)))
+  for key in [key for key, v in table['kernels'].items()
+              if v.get('app') in apps and key not in live]:
+    del table['kernels'][key]
   with open(path, 'w') as f:
     json.dump(table, f, indent=1, sort_keys=True)
   print('wrote', path)
