@@ -1475,17 +1475,56 @@ int soda_hip_run_buffers(soda_hip_plan* plan, soda_hip_buffer_t* const* inputs,
   // sets min / extent / stride of all four dimensions and leaves elem_size
   // alone): a null OUTPUT keeps its min and extents and gets dense strides; a
   // null INPUT gets the first output's min and that output's extents plus the
-  // stencil window minus one (the reference takes the window between the FIRST
-  // input and the first output, core.get_stencil_dim; here it is the composed
-  // window of the first output back to all inputs, which is the same for every
-  // program whose inputs share a window and never smaller).
+  // stencil window minus one, the window being the one between the FIRST input and
+  // the first output (core.get_stencil_dim(get_overall_stencil_window(input 0,
+  // output 0)), host.py:226-233) - for every null input, as in the reference.
   bool query = false;
   auto is_null = [](const soda_hip_buffer_t* b) { return b->host == nullptr && b->dev == 0; };
   for (int j = 0; j < p.n_outputs; ++j) query |= is_null(outputs[j]);
   for (int j = 0; j < p.n_inputs; ++j) query |= is_null(inputs[j]);
   if (query) {
     const soda_hip_buffer_t* o0 = outputs[0];
-    const Box& window = plan->boxes[iterate - 1][p.output_tensor[0]];
+    // As the reference (host.py:226-233): the window between the FIRST input and the
+    // first output, whichever input is asked about - for denoise2d / denoise3d, whose
+    // first input `f` is read at the cell itself only, that is too small for `u`; it
+    // is the reference's answer all the same.  The composed window of `iterate`
+    // iterations with only input 0 as origin:
+    Box window{};
+    {
+      const int nt = n_tensors(p);
+      std::vector<Box> feed(p.n_inputs, Box{});
+      feed[0].set = true;
+      std::vector<Box> cur;
+      for (int it = 0; it < iterate; ++it) {
+        cur.assign(nt, Box{});
+        for (int i = 0; i < p.n_inputs; ++i) cur[i] = feed[i];
+        for (int st = 0; st < p.n_stages; ++st) {
+          const int t = p.n_inputs + st;
+          Box acc{};
+          for (int w = 0; w < p.n_windows; ++w) {
+            const soda_hip_window& win = p.window[w];
+            if (win.stage != t || !cur[win.parent].set) continue;
+            const Box& par = cur[win.parent];
+            for (int d = 0; d < p.dim; ++d) {
+              const int32_t lo = par.lo[d] + win.lo[d], hi = par.hi[d] + win.hi[d];
+              acc.lo[d] = acc.set ? std::min(acc.lo[d], lo) : lo;
+              acc.hi[d] = acc.set ? std::max(acc.hi[d], hi) : hi;
+            }
+            acc.set = true;
+          }
+          for (int d = 0; d < p.dim && acc.set; ++d) {   // boxes contain the cell itself
+            acc.lo[d] = std::min<int32_t>(acc.lo[d], 0);
+            acc.hi[d] = std::max<int32_t>(acc.hi[d], 0);
+          }
+          cur[t] = acc;
+        }
+        if (p.n_inputs == p.n_outputs)
+          for (int j = 0; j < p.n_inputs; ++j) feed[j] = cur[p.output_tensor[j]];
+      }
+      window = cur[p.output_tensor[0]];
+      if (!window.set)      // the first output does not depend on the first input
+        window = plan->boxes[iterate - 1][p.output_tensor[0]];
+    }
     for (int j = 0; j < p.n_outputs; ++j) {
       soda_hip_buffer_t* b = outputs[j];
       if (!is_null(b)) continue;

@@ -676,6 +676,15 @@ def test_bounds_query_mode(capfd):
   ob, ib = _buffer(extent=(64, 48)), _buffer()
   assert _run_buffers(pb, [ib], [ob], 1) == 0
   assert list(ib.extent) == [66, 50, 0, 0]
+  # two inputs: EVERY null input gets the window between the FIRST input and the first
+  # output (reference host.py:226-233) - denoise2d reads its first input `f` at the
+  # cell itself only, so both answers are the output's own extents, too small for `u`
+  # (whose window is 5 x 5): the reference's answer, reproduced
+  pd = program('denoise2d')
+  od, i_f, i_u = _buffer(extent=(64, 48), min_=(2, 3)), _buffer(), _buffer()
+  assert _run_buffers(pd, [i_f, i_u], [od], 1) == 0
+  assert list(i_f.extent) == [64, 48, 0, 0] and list(i_u.extent) == [64, 48, 0, 0]
+  assert list(i_u.min) == [2, 3, 0, 0] and list(i_u.stride) == [1, 64, 0, 0]
   captured = capfd.readouterr()
   assert 'Kernel execution time' not in captured.out
 
