@@ -147,8 +147,19 @@ def kernel_name(spec, depth):
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
          vgpr_budget=244, waves_per_eu=0, bpermute=0, skip_fill=1, xcd_remap=0, nontemporal=0,
-         align='none'):
-  """Returns (text, kernel table entry) for one fused depth."""
+         align='none', steady=None):
+  """Returns (text, kernel table entry) for one fused depth.
+
+  steady (default: on for depth <= 2, the memory-bound kernels): the rows of a chunk
+  whose loads need no clamping and whose results are all stored run in a loop of their
+  own without the per-row range checks, and whether a strip has lanes that store only
+  some of their columns is decided once per strip (template parameter) instead of per
+  row - per row that is ~45 instead of ~66 instructions for jacobi2d (the hand-written
+  tools/k1bench.hip, the same kernel without any of the guards, runs the 16384^2 sweep
+  in 430 us where the guarded loop takes 463-484)."""
+  if steady is None:
+    steady = depth <= 2
+  steady = bool(steady) and bool(skip_fill)
   types = specmod.tensor_c_types(spec)
   index = tensor_index(spec)
   in_type = spec['inputs'][0]['c_type']
@@ -234,7 +245,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
             % (T_in, vec_in, C, elem))
   emit_line('typedef %s %s __attribute__((ext_vector_type(%d), aligned(%d)));'
             % (T_out, vec_out, C, elem))
-  emit_line('template <bool INTERIOR>')
+  emit_line('template <bool INTERIOR%s>' % (', bool RAGGED' if steady else ''))
   emit_line('DEV void %s_strip(const soda_hip_args& a, const i64 xs, const i64 x,'
             ' const i64 y0, const i64 y1) {' % name)
   emit_line('  const i64 W = a.dims[0], H = a.dims[1];')
@@ -247,6 +258,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
         index[t['name']]))
   emit_line('  %s* __restrict__ g_out = (%s*)a.tensor[%d];' % (
       T_out, T_out, index[out_name]))
+  if steady:
+    emit_line('  const bool st_full = x >= st_lo && x + %d <= st_hi;' % C)
   for inst in insts:
     if inst.keep:
       emit_line('  %s %s[%d][%d];' % (builtin_type(inst.c_type), inst.ident,
@@ -280,14 +293,17 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
       return 'from_lane_below%s(%s[%d])' % (suffix, row, C + j)
     return 'from_lane_above%s(%s[%d])' % (suffix, row, j - C)
 
-  def emit_body(guarded):
+  def emit_body(guarded, calm=False):
+    """calm: the steady-state copy - every row loaded lies inside the array, every
+    row produced is stored."""
     for u in range(period):
       emit_line('    {  // unrolled step %d' % u)
       for inst in insts:
         if inst.stage is None:
           s = slot(inst, u, 0)
           emit_line('      {  // load row head+%d of %s' % (u, inst.tensor))
-          emit_line('        i64 row = head + %d; if (row > H - 1) row = H - 1;' % u)
+          emit_line('        i64 row = head + %d;%s' % (
+              u, '' if calm else ' if (row > H - 1) row = H - 1;'))
           emit_line('        const %s* p = g_%s + row * W + x;' % (
               builtin_type(inst.c_type), inst.tensor))
           emit_line('        if (INTERIOR) {')
@@ -325,9 +341,12 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
         if inst.final:
           emit_line('      {  // store row head+%d-%d' % (u, L))
           emit_line('        const i64 y = head + %d;' % (u - L))
-          emit_line('        if (y >= y0 && y < y1) {')
+          emit_line('        %s{' % ('' if calm else 'if (y >= y0 && y < y1) '))
           emit_line('          %s* q = g_out + y * W + x;' % T_out)
-          emit_line('          if (x >= st_lo && x + %d <= st_hi) {' % C)
+          if calm:
+            emit_line('          if (RAGGED ? (x >= st_lo && x + %d <= st_hi) : st_full) {' % C)
+          else:
+            emit_line('          if (x >= st_lo && x + %d <= st_hi) {' % C)
           emit_line('            %s v;' % vec_out)
           for c in range(C):
             emit_line('            v[%d] = out_row[%d];' % (c, c))
@@ -335,7 +354,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
             emit_line('            __builtin_nontemporal_store(v, (%s*)q);' % vec_out)
           else:
             emit_line('            *(%s*)q = v;' % vec_out)
-          emit_line('          } else {')
+          emit_line('          } else %s{' % ('if (RAGGED) ' if calm else ''))
           for c in range(C):
             emit_line('            if (x + %d >= st_lo && x + %d < st_hi) q[%d] = '
                       'out_row[%d];' % (c, c, c, c))
@@ -351,6 +370,18 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
     emit_line('  for (; n < %d && n < steps; n += %d, head += %d) {'
               % (prologue_steps, period, period))
     emit_body(True)
+    emit_line('  }')
+  if steady and prologue_steps:
+    # after the fill every row produced is stored (the prologue ends at a multiple of
+    # the period past the first stored row); rows are loaded unclamped while
+    # head + period - 1 <= H - 1
+    emit_line('  {')
+    emit_line('    const i64 in_array = H - y0 + %d;      // steps whose load row exists'
+              % geo['y_lo'])
+    emit_line('    const i64 calm_end = steps < in_array ? steps : in_array;')
+    emit_line('    for (; n + %d <= calm_end; n += %d, head += %d) {' % (period, period, period))
+    emit_body(False, calm=True)
+    emit_line('    }')
     emit_line('  }')
   emit_line('  for (; n < steps; n += %d, head += %d) {' % (period, period))
   emit_body(False)
@@ -398,8 +429,21 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
   emit_line('  const i64 y1 = y0 + chunk < a.box_hi[1] ? y0 + chunk : a.box_hi[1];')
   emit_line('  const bool interior = xs - %d >= 0 && xs - %d + %d <= a.dims[0];'
             % (geo['halo_lo'], geo['halo_lo'], LANES * C))
-  emit_line('  if (interior) %s_strip<true>(a, xs, x, y0, y1);' % name)
-  emit_line('  else %s_strip<false>(a, xs, x, y0, y1);' % name)
+  if steady:
+    # lanes that store only some of their columns: strips at the box's x edges when
+    # the box does not start / end on a lane boundary
+    emit_line('  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];')
+    emit_line('  const i64 st_hi = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];'
+              % (geo['w_out'], geo['w_out']))
+    emit_line('  const bool partial = !(x >= st_lo && x + %d <= st_hi) && (%s);' % (
+        C, ' || '.join('(x + %d >= st_lo && x + %d < st_hi)' % (c, c) for c in range(C))))
+    emit_line('  const bool ragged = __builtin_amdgcn_ballot_w64(partial) != 0;')
+    emit_line('  if (!interior) %s_strip<false, true>(a, xs, x, y0, y1);' % name)
+    emit_line('  else if (ragged) %s_strip<true, true>(a, xs, x, y0, y1);' % name)
+    emit_line('  else %s_strip<true, false>(a, xs, x, y0, y1);' % name)
+  else:
+    emit_line('  if (interior) %s_strip<true>(a, xs, x, y0, y1);' % name)
+    emit_line('  else %s_strip<false>(a, xs, x, y0, y1);' % name)
   emit_line('}')
   entry = dict(name=name, kind='fused', depth=depth, stage=-1,
                block=[WAVES_PER_BLOCK * LANES, 1, 1],
@@ -407,5 +451,6 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
                origin_align=geo['origin_align'],
                fill_rows=L + geo['y_lo'],
                cols=C, prefetch=prefetch, period=period, est_vgprs=est_vgprs,
-               halo=[geo['halo_lo'], geo['halo_hi']], w_out=geo['w_out'])
+               halo=[geo['halo_lo'], geo['halo_hi']], w_out=geo['w_out'],
+               steady=int(steady))
   return '\n'.join(o) + '\n', entry

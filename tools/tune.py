@@ -30,7 +30,10 @@ for variant in sys.argv[4:]:
   t0 = time.time()
   if 'wave_groups' not in extra:
     extra.setdefault('vgpr_budget', 400)
+  noflags = extra.pop('noflags', 0)     # compile without the per-program -mllvm flags
   text, table = kernel.generate(spec, depths=[depth], cols=cols, chunk_rows=chunk, prefetch=pf, **extra)
+  if noflags:
+    text = '\n'.join(l for l in text.split('\n') if not l.startswith(kernel.FLAGS_MARK))
   try:
     if os.environ.get('TUNE_HIPCC'):     # offline compile, as the shipped blobs
       path = '/tmp/tune_%d.hsaco' % os.getpid()
