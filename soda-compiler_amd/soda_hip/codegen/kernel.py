@@ -71,6 +71,14 @@ DEEP_3D_DEPTHS = (4,)
 # in the wave-pipelined form): 392 vs 378 us per 512^3 launch.
 DEEP_3D_FORM = 'both'
 BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300)
+# The block form's input planes: through a two-slot LDS ring (LDS-direct loads, no
+# prefetch registers) where the program's edge rows leave the LDS for it, else one
+# plane ahead in registers.  Per depth-4 launch inside the 512^3 array of cfg5 (same
+# chunking): box 496 242 vs 247 us, 456 205 vs 219, 416 152 vs 166, 352 117 vs 130,
+# 256 53 vs 74; heat3d 512^3 x20, block form alone: 1.94 vs 1.96 ms, with the
+# arithmetic as a hand-ordered instruction stream (kernel_asm; pays for programs
+# above PACKED_3D_LIGHT_WEIGHT only) 1.83 vs 1.90 ms (profiles/r03_blk_variants.txt).
+BLOCK_3D_RING_OPTIONS = dict(stack=8, prefetch=0, ring=2, vgpr_budget=300)
 # ... for programs light enough on arithmetic: jacobi3d (weight 7) 417 us per
 # depth-4 launch against 2 x 374 us at depth 2, heat3d (15) 622 us against
 # 2 x 411 us; heavier programs are VALU-bound at depth 2 already
@@ -479,10 +487,21 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
           # block form: all levels in every wavefront, edge rows through LDS
           # (kernel_stream3d_blk).  Named <app>_fused_k<d>b; with 'both' it ships
           # NEXT TO the wave-pipelined kernel and the run-time picks per launch
-          options = dict(BLOCK_3D_OPTIONS)
-          options.update(prefixed_options(fused_options, 'blk_', kernel_stream3d_blk.emit))
+          given = prefixed_options(fused_options, 'blk_', kernel_stream3d_blk.emit)
+          attempts = [BLOCK_3D_OPTIONS] if 'prefetch' in given or 'ring' in given else \
+              [BLOCK_3D_RING_OPTIONS, BLOCK_3D_OPTIONS]
           try:
-            ftext, entry = kernel_stream3d_blk.emit(spec, depth, **options)
+            for k, base in enumerate(attempts):
+              options = dict(base, asm_sched=int(
+                  base.get('ring', 0) > 0 and
+                  arithmetic_weight(spec) > PACKED_3D_LIGHT_WEIGHT))
+              options.update(given)
+              try:
+                ftext, entry = kernel_stream3d_blk.emit(spec, depth, **options)
+                break
+              except kernel_stream2d.NotFusable:
+                if k == len(attempts) - 1:
+                  raise
             parts.append(ftext)
             table.append(annotate_cost(entry, spec))
             if form == 'blk':

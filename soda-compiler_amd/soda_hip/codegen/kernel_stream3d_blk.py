@@ -94,7 +94,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
          max_period=12, vgpr_budget=250, waves_per_eu=0, xcd_tiles=1, ring=0,
          pairs=0, align_out=16, xcd_runs=1, stamps=0,
          flat_stores=2, skip_fill=0, fence=1, asm_sched=0, asm_group=4,
-         edge_ahead=1):
+         edge_ahead=1, mask_loads=0):
   """Returns (text, kernel table entry).
 
   `prefetch` = input planes loaded ahead into REGISTERS (R*C VGPRs each);
@@ -375,6 +375,18 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   else:
     line('  const bool st_ragged = __builtin_amdgcn_ballot_w64(!st_full && (%s)) != 0;'
          % ' || '.join('st_col%d' % c for c in range(C)))
+  if mask_loads and not ring:
+    # a ragged tile reads only what some stored cell depends on: lanes right of the
+    # box's reach "load" out of range (a loop-invariant offset), rows below it lie
+    # past the record count of the plane's resource - neither costs an instruction
+    # in the loop, and what they would have fetched is never moved
+    line('  const unsigned ld_lane_byte = x < a.box_hi[0] + %d ? lane_byte : 0xfffffff0u;'
+         % hi[0])
+    line('  const i64 ld_rows = a.box_hi[1] + %d < H ? a.box_hi[1] + %d : H;' % (hi[1], hi[1]))
+    line('  const i64 ld_plane_bytes = ld_rows * W * %d;' % elem)
+  else:
+    line('  const unsigned ld_lane_byte = lane_byte;')
+    line('  const i64 ld_plane_bytes = plane_bytes;')
   line('  const %s* __restrict__ g_in = (const %s*)a.tensor[%d];'
        % (T, T, index[spec['inputs'][0]['name']]))
   line('  %s* __restrict__ g_out = (%s*)a.tensor[%d];' % (T, T, index[out_name]))
@@ -539,7 +551,12 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
         # plane head+u was issued `ring` steps ago; since then this wavefront has
         # issued ring-1 planes of loads and `ring` steps of (at least) R stores
         wait = (ring - 1) * ring_loads + ring * R
-        line('      __builtin_amdgcn_s_waitcnt(%d);  // vmcnt(%d)' % (vmcnt(wait), wait))
+        if flat_stores == 2:     # the ragged instantiation stores column by column
+          ragged_wait = (ring - 1) * ring_loads + ring * R * C
+          line('      __builtin_amdgcn_s_waitcnt(RAGGED ? %d : %d);  // vmcnt(%d / %d)' % (
+              vmcnt(min(63, ragged_wait)), vmcnt(wait), min(63, ragged_wait), wait))
+        else:
+          line('      __builtin_amdgcn_s_waitcnt(%d);  // vmcnt(%d)' % (vmcnt(wait), wait))
         line('      { %s t[%d][%d];' % (T, R, C))
         line('        soda_ring_read_%s(&in_ring[%d][wave][0][lane * %d], %s);' % (
             name, u % ring, C, ', '.join('t[%d][%d]' % (r, c)
@@ -558,16 +575,16 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
         oob = skip_fill == 3 and not ring
         if oob:      # no branch: planes nobody needs are "loaded" out of range
           cond = None
-          line('      const unsigned ld_byte_%d = n + %d < span + %d ? lane_byte : '
+          line('      const unsigned ld_byte_%d = n + %d < span + %d ? ld_lane_byte : '
                '0xfffffff0u;' % (u, u, lo[2] + inst.lag + inst.need_hi))
         line('      %s{ i64 zz = head + %d; if (zz > D - 1) zz = D - 1;' % (
             'if (%s) ' % cond if cond else '', u))
         line('        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
-             'rsrc((void*)(g_in + zz * plane), 0, (int)plane_bytes, 0x27000);')
+             'rsrc((void*)(g_in + zz * plane), 0, (int)ld_plane_bytes, 0x27000);')
         for r in range(R):
           line('        { const %s v = __builtin_bit_cast(%s, __builtin_amdgcn_raw_'
                'buffer_load_%s(rs, %s, (unsigned)(%d * W * %d), 0));%s }' % (
-                   vec, vec, suffix, 'ld_byte_%d' % u if oob else 'lane_byte', r, elem,
+                   vec, vec, suffix, 'ld_byte_%d' % u if oob else 'ld_lane_byte', r, elem,
                    ''.join(
                        ' %s = v[%d];' % (cell(inst.ident, s, r, c), c)
                        for c in range(C))))
@@ -611,7 +628,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
                               prefix='a%d_%d' % (u, insts.index(inst)))
       if inst.up or inst.down:
         publish(inst, u, slot(inst, u, 0))
-      if inst.final and flat_stores == 2 and not ring:
+      if inst.final and flat_stores == 2:
         line('        const i64 z = head + %d;' % (u - L))
         line('        const bool z_ok = z >= z0 && z < z1;')
         line('        const unsigned rows_now = z_ok ? st_rows : 0u;')

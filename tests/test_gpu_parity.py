@@ -266,7 +266,10 @@ def test_3d_wave_pipelined_forms_on_heat3d(options):
 
 
 @pytest.mark.parametrize('app,options', [
-    ('jacobi3d', dict(deep3d='blk')),                      # 8 bands, prefetch 1
+    ('jacobi3d', dict(deep3d='blk')),                      # 8 bands, LDS ring of 2 planes
+    ('jacobi3d', dict(deep3d='blk', blk_prefetch=1)),      # ... one plane ahead in registers
+    ('heat3d', dict(deep3d='blk')),                        # ring + hand-ordered arithmetic
+    ('jacobi3d', dict(deep3d='blk', blk_prefetch=1, blk_mask_loads=1)),
     ('jacobi3d', dict(deep3d='blk', blk_stack=4, blk_prefetch=0)),
     ('jacobi3d', dict(deep3d='blk', blk_stack=8, blk_rows=4, blk_prefetch=2)),
     # packed pair-rows; input planes through per-wavefront LDS rings (counted waits)
@@ -278,12 +281,13 @@ def test_3d_wave_pipelined_forms_on_heat3d(options):
     # fences and the next level's edge rows read ahead; the older store paths, the
     # hand-ordered arithmetic (kernel_asm), the fill-skipping variants and unaligned
     # tiles in plain order stay correct
-    ('jacobi3d', dict(deep3d='blk', blk_flat_stores=0, blk_fence=0, blk_edge_ahead=0)),
-    ('jacobi3d', dict(deep3d='blk', blk_flat_stores=1, blk_edge_ahead=2)),
+    ('jacobi3d', dict(deep3d='blk', blk_prefetch=1, blk_flat_stores=0, blk_fence=0,
+                      blk_edge_ahead=0)),
+    ('jacobi3d', dict(deep3d='blk', blk_prefetch=1, blk_flat_stores=1, blk_edge_ahead=2)),
     ('jacobi3d', dict(deep3d='blk', blk_asm_sched=1)),
-    ('heat3d', dict(deep3d='blk', blk_asm_sched=1, blk_asm_group=8)),
-    ('jacobi3d', dict(deep3d='blk', blk_skip_fill=1, blk_flat_stores=0)),
-    ('heat3d', dict(deep3d='blk', blk_skip_fill=3)),
+    ('heat3d', dict(deep3d='blk', blk_prefetch=1, blk_asm_sched=1, blk_asm_group=8)),
+    ('jacobi3d', dict(deep3d='blk', blk_prefetch=1, blk_skip_fill=1, blk_flat_stores=0)),
+    ('heat3d', dict(deep3d='blk', blk_prefetch=1, blk_skip_fill=3)),
     ('jacobi3d', dict(deep3d='blk', blk_align_out=2, blk_xcd_runs=0)),
     ('jacobi3d', dict(deep3d='blk', blk_align_out=32))])
 def test_3d_block_form(app, options):

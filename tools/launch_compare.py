@@ -39,9 +39,10 @@ for variant in sys.argv[4:]:
   env = dict(os.environ, SODA_HIP_TUNING='1', SODA_HIP_LAUNCH_TRACE='1')
   p = subprocess.run([sys.executable, __file__, '--child', app, n, iterate, variant],
                      env=env, capture_output=True, text=True)
-  launches = [(m.group(2), float(m.group(3)), float(m.group(4)), m.group(5))
-              for m in re.finditer(r'launch\s+(\d+) (\S+)\s+([\d.]+) us \(model\s+([\d.]+)\)  box (\S+ x \S+ x \S+)',
-                                   p.stderr)]
+  launches = [(m.group(2), float(m.group(3)), float(m.group(4)), m.group(5),
+               '%sx%s' % (m.group(6), m.group(7)))
+              for m in re.finditer(r'launch\s+(\d+) (\S+)\s+([\d.]+) us \(model\s+([\d.]+)\)  box (\S+ x \S+ x \S+)'
+                                   r'\s+grid (\d+) x \d+ x \d+\s+chunk (\d+)', p.stderr)]
   total = re.search(r'TOTAL ([\d.]+)', p.stdout)
   if not launches:
     print(variant, 'FAILED', p.stderr[-400:])
@@ -56,6 +57,6 @@ if len(runs) > 1 and len({len(r[1]) for r in runs}) == 1:
     cells = [r[1][i] for r in runs]
     best_sum += min(c[1] for c in cells[1:]) if len(cells) > 1 else cells[0][1]
     print('%3d  %-18s' % (i, cells[0][3]) + ''.join(
-        '  %-5s %7.1f us (model %6.1f)' % (c[0].split('_fused_')[-1], c[1], c[2])
+        '  %-5s %7.1f us (model %6.1f) %-9s' % (c[0].split('_fused_')[-1], c[1], c[2], c[4])
         for c in cells))
   print('best single-kernel choice per launch (columns 2..): %.1f us' % best_sum)
