@@ -60,6 +60,8 @@ WAVE_PIPELINE_MIN_DEPTH = 4
 # nothing at 4, a loss from depth 8 on where the VALU bounds and the extra halo
 # columns cost more than the alignment saves).
 ALIGN_FULL_MAX_DEPTH = 2
+# ... and their stores bypass the caches on arrays beyond the Infinity Cache
+NT_AUTO_MAX_DEPTH_2D = 2
 # 3-D: depths beyond the single-wave form, built wave-pipelined (kernel_stream3d_wp)
 DEEP_3D_DEPTHS = (4,)
 # 3-D programs light on arithmetic get TWO depth-4 kernels: the wave-pipelined one
@@ -70,7 +72,7 @@ DEEP_3D_DEPTHS = (4,)
 # ms with either alone, 5.87 ms with the per-launch choice.  heat3d (packed pair-rows
 # in the wave-pipelined form): 392 vs 378 us per 512^3 launch.
 DEEP_3D_FORM = 'both'
-BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300)
+BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300, nt=4)
 # The block form's input planes: through a two-slot LDS ring (LDS-direct loads, no
 # prefetch registers) where the program's edge rows leave the LDS for it, else one
 # plane ahead in registers.  Per depth-4 launch inside the 512^3 array of cfg5 (same
@@ -78,7 +80,7 @@ BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300)
 # 256 53 vs 74; heat3d 512^3 x20, block form alone: 1.94 vs 1.96 ms, with the
 # arithmetic as a hand-ordered instruction stream (kernel_asm; pays for programs
 # above PACKED_3D_LIGHT_WEIGHT only) 1.83 vs 1.90 ms (profiles/r03_blk_variants.txt).
-BLOCK_3D_RING_OPTIONS = dict(stack=8, prefetch=0, ring=2, vgpr_budget=300)
+BLOCK_3D_RING_OPTIONS = dict(stack=8, prefetch=0, ring=2, vgpr_budget=300, nt=4)
 # ... for programs light enough on arithmetic: jacobi3d (weight 7) 417 us per
 # depth-4 launch against 2 x 374 us at depth 2, heat3d (15) 622 us against
 # 2 x 411 us; heavier programs are VALU-bound at depth 2 already
@@ -93,7 +95,7 @@ ALIGN_FULL_MAX_WEIGHT = 40
 # those both forms understand, and those only the wave-pipelined form has
 SHARED_2D_OPTIONS = ('skip_fill', 'vgpr_budget', 'max_period', 'align', 'waves_per_eu')
 WP_ONLY_OPTIONS = ('pairs', 'ring', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store',
-                   'prio', 'rotate')
+                   'prio', 'rotate', 'ntstore')
 
 HIPCC_FLAGS = ['-x', 'hip', '--offload-arch=gfx950', '--cuda-device-only',
                '--no-gpu-bundle-output', '-O3', '-ffp-contract=off',
@@ -371,10 +373,13 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
         pass
       elif groups <= 1 or depth < WAVE_PIPELINE_MIN_DEPTH or groups == -1:
         try:
+          # the memory-bound depths store around the caches when a launch's box
+          # does not fit the Infinity Cache (kernel_stream2d.emit: nontemporal)
           single = kernel_stream2d.emit(
               spec, depth, **common,
-              **{k: v for k, v in fused_options.items()
-                 if k not in WP_ONLY_OPTIONS and not k.startswith('k1_')})
+              **dict({'nontemporal': 4} if depth <= NT_AUTO_MAX_DEPTH_2D else {},
+                     **{k: v for k, v in fused_options.items()
+                        if k not in WP_ONLY_OPTIONS and not k.startswith('k1_')}))
         except kernel_stream2d.NotFusable as e:
           notes.append('depth %d not fused: %s' % (depth, e))
       want_piped = piped is None and depth >= WAVE_PIPELINE_MIN_DEPTH and (
@@ -463,6 +468,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
       shapes = [(options.pop('rows'), cols or 2)] if 'rows' in options else \
           [(16, cols or 2), (12, cols or 2)] + narrow
       error = None
+      options.setdefault('nt', 4)
       for rows, lane_cols in shapes:
         try:
           ftext, entry = kernel_stream3d.emit(spec, depth, rows=rows, cols=lane_cols,
@@ -510,6 +516,8 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
             notes.append('depth %d not in block form: %s' % (depth, e))
         options = prefixed_options(fused_options, 'wp_', kernel_stream3d_wp.emit)
         options.setdefault('groups', min(depth * len(spec['stages']), 4))
+        # (no non-temporal stores here: heat3d 512^3 x20 with this form alone 2.09 ms
+        # without, 2.12 ms with wp_nt=4)
         if options.get('split', 2) == 2 and not options.get('loader') and \
             options.get('rows', 16) % 2 == 0 and kernel_stream2d_wp.packable(spec):
           # packed pair-rows (v_pk_*_f32) for programs heavy enough on arithmetic:

@@ -14,6 +14,13 @@ from . import spec as specmod
 
 ABI_VERSION = 4
 
+# A launch whose box (inputs + outputs) is larger than this streams: nothing it writes
+# is still cached when the next launch reads it, and its stores go out non-temporal
+# (the MI355X's Infinity Cache holds 256 MiB; measured cross-over of the 3-D block
+# form between boxes of 262 MB, where bypassing costs 5 %, and 325 MB, where it gains
+# 5 %: profiles/r03_blk_variants.txt)
+NT_STREAMING_BYTES = 288 * 1024 * 1024
+
 # element types as builtin spellings (no <stdint.h> in the translation unit)
 BUILTIN_TYPE = {
     'uint8_t': 'unsigned char', 'int8_t': 'signed char',

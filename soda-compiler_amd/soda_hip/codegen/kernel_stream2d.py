@@ -26,6 +26,7 @@ Mapping (gfx950, wave64):
 Cost model per cell-update (jacobi2d): 5 VALU lane-ops, 8/depth bytes of HBM.
 """
 
+from . import kernel_common
 from . import spec as specmod
 from .kernel_common import builtin_type, cell_assignment, device_expr, tensor_index
 
@@ -245,7 +246,14 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
             % (T_in, vec_in, C, elem))
   emit_line('typedef %s %s __attribute__((ext_vector_type(%d), aligned(%d)));'
             % (T_out, vec_out, C, elem))
-  emit_line('template <bool INTERIOR%s>' % (', bool RAGGED' if steady else ''))
+  # nontemporal: 1 = loads, 2 = stores, 4 = the stores of launches whose box does not
+  # fit the Infinity Cache (kernel_common.NT_STREAMING_BYTES), as an instantiation of
+  # the steady interior path chosen per launch.  Per launch at 16384^2, stores always /
+  # never non-temporal: blur 222 vs 233 us, jacobi2d depth 1 452 vs 470, depth 2 464 vs
+  # 476, sobel2d 263 vs 268, seidel2d depth 4 516 vs 511 (profiles/r03_k1bench.txt)
+  nt_auto = bool(nontemporal & 4) and steady
+  emit_line('template <bool INTERIOR%s%s>' % (', bool RAGGED' if steady else '',
+                                              ', bool NT = false' if nt_auto else ''))
   emit_line('DEV void %s_strip(const soda_hip_args& a, const i64 xs, const i64 x,'
             ' const i64 y0, const i64 y1) {' % name)
   emit_line('  const i64 W = a.dims[0], H = a.dims[1];')
@@ -307,7 +315,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
           emit_line('        const %s* p = g_%s + row * W + x;' % (
               builtin_type(inst.c_type), inst.tensor))
           emit_line('        if (INTERIOR) {')
-          if nontemporal:
+          if nontemporal & 1:
             emit_line('          const %s v = __builtin_nontemporal_load((const %s*)p);'
                       % (vec_in, vec_in))
           else:
@@ -350,7 +358,10 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
           emit_line('            %s v;' % vec_out)
           for c in range(C):
             emit_line('            v[%d] = out_row[%d];' % (c, c))
-          if nontemporal:
+          if nt_auto:
+            emit_line('            if (NT) __builtin_nontemporal_store(v, (%s*)q); '
+                      'else *(%s*)q = v;' % (vec_out, vec_out))
+          elif nontemporal & 2:
             emit_line('            __builtin_nontemporal_store(v, (%s*)q);' % vec_out)
           else:
             emit_line('            *(%s*)q = v;' % vec_out)
@@ -440,6 +451,13 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
     emit_line('  const bool ragged = __builtin_amdgcn_ballot_w64(partial) != 0;')
     emit_line('  if (!interior) %s_strip<false, true>(a, xs, x, y0, y1);' % name)
     emit_line('  else if (ragged) %s_strip<true, true>(a, xs, x, y0, y1);' % name)
+    if nt_auto:
+      types = specmod.tensor_c_types(spec)
+      cell_bytes = sum(specmod.ELEM_SIZE[types[n]] for n in
+                       [t['name'] for t in spec['inputs']] + list(spec['outputs']))
+      emit_line('  else if ((a.box_hi[0] - a.box_lo[0]) * (a.box_hi[1] - a.box_lo[1]) * %d > '
+                '%dll) %s_strip<true, false, true>(a, xs, x, y0, y1);' % (
+                    cell_bytes, kernel_common.NT_STREAMING_BYTES, name))
     emit_line('  else %s_strip<true, false>(a, xs, x, y0, y1);' % name)
   else:
     emit_line('  if (interior) %s_strip<true>(a, xs, x, y0, y1);' % name)
@@ -453,4 +471,6 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
                cols=C, prefetch=prefetch, period=period, est_vgprs=est_vgprs,
                halo=[geo['halo_lo'], geo['halo_hi']], w_out=geo['w_out'],
                steady=int(steady))
+  if nontemporal:
+    entry['nontemporal'] = int(nontemporal)
   return '\n'.join(o) + '\n', entry

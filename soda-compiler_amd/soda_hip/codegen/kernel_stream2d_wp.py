@@ -163,7 +163,7 @@ def packable(spec):
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
          max_period=12, vgpr_budget=120, skip_fill=1, pairs=0, align='none',
-         ring=0, waves_per_eu=0, dppadd=0, split=None, sync=1, ringpk=1, fast_store=1, prio=None, rotate=0):
+         ring=0, waves_per_eu=0, dppadd=0, split=None, sync=1, ringpk=1, fast_store=1, prio=None, rotate=0, ntstore=0):
   """Returns (text, kernel table entry).
 
   pairs=2 (needs the ring): ONE strip of 2 x 64 x C columns per wavefront; a
@@ -427,6 +427,12 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
           for half in range(P):
             sel = '[%d]' % half if pairs else ''
             xv = 'xb' if half else 'x'
+            if ntstore:     # (measured only: tools/tune.py ...,ntstore=1)
+              line('              if (full_%d) { %s v;%s __builtin_nontemporal_store(v, '
+                   '(%s*)(g_out + y * W + %s)); }'
+                   % (half, vec, ''.join(' v[%d] = out_row[%d]%s;' % (c, c, sel)
+                                         for c in range(C)), vec, xv))
+              continue
             line('              if (full_%d) { %s v;%s *(%s*)(g_out + y * W + %s) = v; }'
                  % (half, vec, ''.join(' v[%d] = out_row[%d]%s;' % (c, c, sel)
                                        for c in range(C)), vec, xv))

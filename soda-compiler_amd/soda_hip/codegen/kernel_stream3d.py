@@ -20,6 +20,7 @@ of registers (3*R*C per lane).  With R = 16, C = 2 and depth 2 that is ~200
 VGPRs, two waves per SIMD, and HBM sees (4/0.73 + 4)/2 = 4.7 B per update
 instead of 8.
 """
+from . import kernel_common
 from . import spec as specmod
 from .kernel_common import builtin_type, cell_assignment, device_expr, tensor_index
 from .kernel_stream2d import (LANES, WAVES_PER_BLOCK, NotFusable,
@@ -54,8 +55,12 @@ def pipeline(spec, depth, prefetch):
 
 
 def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, max_period=12,
-         vgpr_budget=250, waves_per_eu=0):
-  """Returns (text, kernel table entry) for one fused depth."""
+         vgpr_budget=250, waves_per_eu=0, nt=0):
+  """Returns (text, kernel table entry) for one fused depth.
+
+  nt = 4: launches whose box (all inputs and outputs) is larger than the Infinity
+  Cache store around the caches - a second instantiation of the interior path, chosen
+  by the kernel's entry (kernel_common.NT_STREAMING_BYTES); 2 = always."""
   if spec['dim'] != 3:
     raise NotFusable('stream3d handles 3-D programs')
   if len(spec['outputs']) != 1:
@@ -129,7 +134,7 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, max_period=1
        % (T_in, vec_in, C, elem))
   line('typedef %s %s __attribute__((ext_vector_type(%d), aligned(%d)));'
        % (T_out, vec_out, C, elem))
-  line('template <bool INTERIOR>')
+  line('template <bool INTERIOR, bool NT = %s>' % ('true' if nt & 2 else 'false'))
   line('DEV void %s_tile(const soda_hip_args& a, const i64 xs, const i64 x, '
        'const i64 yb, const i64 z0, const i64 z1) {' % name)
   line('  const i64 W = a.dims[0], H = a.dims[1], D = a.dims[2];')
@@ -229,7 +234,11 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, max_period=1
           line('            if (x >= st_lo && x + %d <= st_hi) {' % C)
           line('              %s v;%s' % (vec_out, ''.join(
               ' v[%d] = out_tile[%d][%d];' % (c, r, c) for c in range(C))))
-          line('              *(%s*)(q + row_y[%d] + x) = v;' % (vec_out, r))
+          if nt & 6:
+            line('              if (NT) __builtin_nontemporal_store(v, (%s*)(q + row_y[%d] + x)); '
+                 'else *(%s*)(q + row_y[%d] + x) = v;' % (vec_out, r, vec_out, r))
+          else:
+            line('              *(%s*)(q + row_y[%d] + x) = v;' % (vec_out, r))
           line('            } else {')
           for c in range(C):
             line('              if (x + %d >= st_lo && x + %d < st_hi) '
@@ -263,7 +272,17 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, max_period=1
   line('  const i64 z1 = z0 + chunk < a.box_hi[2] ? z0 + chunk : a.box_hi[2];')
   line('  const bool interior = xs - %d >= 0 && xs - %d + %d <= a.dims[0];'
        % (halo_lo, halo_lo, LANES * C))
-  line('  if (interior) %s_tile<true>(a, xs, x, yb, z0, z1);' % name)
+  if nt & 4:
+    types = specmod.tensor_c_types(spec)
+    cell_bytes = sum(specmod.ELEM_SIZE[types[n]] for n in
+                     [t['name'] for t in spec['inputs']] + list(spec['outputs']))
+    line('  const bool streaming = (a.box_hi[0] - a.box_lo[0]) * (a.box_hi[1] - a.box_lo[1]) '
+         '* (a.box_hi[2] - a.box_lo[2]) * %d > %dll;' % (
+             cell_bytes, kernel_common.NT_STREAMING_BYTES))
+    line('  if (interior && streaming) %s_tile<true, true>(a, xs, x, yb, z0, z1);' % name)
+    line('  else if (interior) %s_tile<true>(a, xs, x, yb, z0, z1);' % name)
+  else:
+    line('  if (interior) %s_tile<true>(a, xs, x, yb, z0, z1);' % name)
   line('  else %s_tile<false>(a, xs, x, yb, z0, z1);' % name)
   line('}')
   entry = dict(name=name, kind='fused', depth=depth, stage=-1,
@@ -271,4 +290,6 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, max_period=1
                tile=[WAVES_PER_BLOCK * w_out - C, r_out, chunk_planes, 1],
                fill_rows=L + lo[2], cols=C, rows=R, prefetch=prefetch,
                period=period, est_vgprs=est_vgprs, w_out=w_out, r_out=r_out)
+  if nt:
+    entry['nt'] = int(nt)
   return '\n'.join(o) + '\n', entry

@@ -38,6 +38,7 @@ Scope: one input, one output, 4-byte elements, x offsets within C columns,
 y offsets within R rows.
 """
 from . import kernel_asm
+from . import kernel_common
 from . import spec as specmod
 from .kernel_common import builtin_type, cell_assignment, device_expr, tensor_index
 from .kernel_stream2d import LANES, Instance, NotFusable
@@ -94,7 +95,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
          max_period=12, vgpr_budget=250, waves_per_eu=0, xcd_tiles=1, ring=0,
          pairs=0, align_out=16, xcd_runs=1, stamps=0,
          flat_stores=2, skip_fill=0, fence=1, asm_sched=0, asm_group=4,
-         edge_ahead=1, mask_loads=0):
+         edge_ahead=1, mask_loads=0, nt=0):
   """Returns (text, kernel table entry).
 
   `prefetch` = input planes loaded ahead into REGISTERS (R*C VGPRs each);
@@ -336,8 +337,9 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     for r in range(R):
       line('  ' + ' '.join('v%d_%d = t%d[%d];' % (r, c, r, c) for c in range(C)))
     line('}')
+  nt_auto = bool(nt & 4) and flat_stores == 2
   if flat_stores == 2:
-    line('template <bool RAGGED>')
+    line('template <bool RAGGED%s>' % (', bool NT' if nt_auto else ''))
   line('DEV void %s_band(const soda_hip_args& a, const i64 xs, const i64 yb, '
        'const i64 wx, const i64 wy, const i64 z0, const i64 z1, const int wave, '
        'const int lane, %s (*edges)[%d][%d][%d][%d], %s (*in_ring)[%d][%d][%d]) {'
@@ -421,14 +423,20 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     parts.append('n + %d < span + %d' % (u, last))
     return ' && '.join(parts)
 
+  # `nt`: the non-temporal bit (aux bit 1) on the output stores (2) / the input loads
+  # (1); 4 = on the stores of launches whose box does not fit the Infinity Cache (an
+  # instantiation of its own, chosen per launch by the kernel's entry)
+  st_aux = 'NT ? 2 : 0' if nt_auto else '2' if nt & 2 else '0'
+  ld_aux = 2 if nt & 1 else 0
+
   def ring_load(slot_index, plane_expr, indent):
     line(indent + '{ i64 zz = %s; if (zz > D - 1) zz = D - 1;' % plane_expr)
     line(indent + '  const %s* p = g_in + zz * plane + dma_lane;' % T)
     for i in range(ring_loads):
       line(indent + '  __builtin_amdgcn_global_load_lds((const __attribute__(('
            'address_space(1))) void*)(p + %d * W), (__attribute__((address_space(3)))'
-           ' void*)&in_ring[%d][wave][%d][0], 16, 0, 0);' % (
-               i * rows_per_load, slot_index, i * rows_per_load))
+           ' void*)&in_ring[%d][wave][%d][0], 16, 0, %d);' % (
+               i * rows_per_load, slot_index, i * rows_per_load, ld_aux))
     line(indent + '}')
 
   if ring:
@@ -583,8 +591,9 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
              'rsrc((void*)(g_in + zz * plane), 0, (int)ld_plane_bytes, 0x27000);')
         for r in range(R):
           line('        { const %s v = __builtin_bit_cast(%s, __builtin_amdgcn_raw_'
-               'buffer_load_%s(rs, %s, (unsigned)(%d * W * %d), 0));%s }' % (
+               'buffer_load_%s(rs, %s, (unsigned)(%d * W * %d), %d));%s }' % (
                    vec, vec, suffix, 'ld_byte_%d' % u if oob else 'ld_lane_byte', r, elem,
+                   ld_aux,
                    ''.join(
                        ' %s = v[%d];' % (cell(inst.ident, s, r, c), c)
                        for c in range(C))))
@@ -638,12 +647,12 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
                'rsrc((void*)out_plane, 0, (rows_now >> %d) & 1u ? (int)plane_bytes : 0, '
                '0x27000);' % r)
           line('          if (!RAGGED) { %s v;%s __builtin_amdgcn_raw_buffer_store_%s('
-               '__builtin_bit_cast(%s, v), rs, st_voff, (unsigned)(%d * W * %d), 0); }' % (
+               '__builtin_bit_cast(%s, v), rs, st_voff, (unsigned)(%d * W * %d), %s); }' % (
                    vec, ''.join(' v[%d] = %s;' % (c, out_cell(r, c))
-                                for c in range(C)), suffix, buf_type, r, elem))
+                                for c in range(C)), suffix, buf_type, r, elem, st_aux))
           line('          else {%s }' % ''.join(
               ' __builtin_amdgcn_raw_buffer_store_b32(%s_bits(%s), rs, st_voff%d, '
-              '(unsigned)(%d * W * %d), 0);' % (name, out_cell(r, c), c, r, elem)
+              '(unsigned)(%d * W * %d), %s);' % (name, out_cell(r, c), c, r, elem, st_aux)
               for c in range(C)))
           line('        }')
       elif inst.final and (ring or flat_stores):
@@ -761,12 +770,26 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
          % (w_out, w_out))
     line('  const bool partial = !(x >= st_lo && x + %d <= st_hi) && (%s);' % (
         C, ' || '.join('(x + %d >= st_lo && x + %d < st_hi)' % (c, c) for c in range(C))))
-    line('  if (__builtin_amdgcn_ballot_w64(partial) != 0)')
-    line('    %s_band<true>(a, xs, yb, wx, wy, z0, z1, wave, lane, edges, %s);'
-         % (name, 'in_ring' if ring else 'nullptr'))
-    line('  else')
-    line('    %s_band<false>(a, xs, yb, wx, wy, z0, z1, wave, lane, edges, %s);'
-         % (name, 'in_ring' if ring else 'nullptr'))
+    call = '%s_band<%%s>(a, xs, yb, wx, wy, z0, z1, wave, lane, edges, %s);' % (
+        name, 'in_ring' if ring else 'nullptr')
+    if nt_auto:
+      # a box (input + output) beyond the Infinity Cache: its stores bypass the caches
+      # (kernel_common.NT_STREAMING_BYTES; jacobi3d per launch inside a 512^3 array,
+      # always / never: box 496 222 vs 246 us, 448 161 vs 176, 400 141 vs 153, 344 106
+      # vs 111, 320 85 vs 81, 224 46 vs 40, 112 35 vs 35)
+      line('  const bool streaming = (a.box_hi[0] - a.box_lo[0]) * (a.box_hi[1] - '
+           'a.box_lo[1]) * (a.box_hi[2] - a.box_lo[2]) * %d > %dll;' % (
+               2 * elem, kernel_common.NT_STREAMING_BYTES))
+      line('  const bool ragged = __builtin_amdgcn_ballot_w64(partial) != 0;')
+      line('  if (streaming) { if (ragged) %s else %s }' % (call % 'true, true',
+                                                           call % 'false, true'))
+      line('  else { if (ragged) %s else %s }' % (call % 'true, false',
+                                                  call % 'false, false'))
+    else:
+      line('  if (__builtin_amdgcn_ballot_w64(partial) != 0)')
+      line('    ' + call % 'true')
+      line('  else')
+      line('    ' + call % 'false')
   else:
     line('  %s_band(a, xs, yb, wx, wy, z0, z1, wave, lane, edges, %s);'
          % (name, 'in_ring' if ring else 'nullptr'))
@@ -781,4 +804,8 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
                asm_sched=int(bool(asm_sched and not pairs)),
                flat_stores=int(flat_stores),
                min_extent=[LANES * C, TR])
+  if nt:                    # (only when set: the shipped kernels' calibration keys stay)
+    entry['nt'] = int(nt)
+  if mask_loads and not ring:
+    entry['mask_loads'] = 1
   return '\n'.join(o) + '\n', entry

@@ -19,6 +19,7 @@ Scope: single-input single-output chains in which a group reads only itself
 and the last instance of the previous group; anything else keeps the
 single-wave form.
 """
+from . import kernel_common
 from . import spec as specmod
 from .kernel_common import builtin_type, cell_assignment, device_expr, tensor_index
 from .kernel_stream2d import LANES, NotFusable
@@ -29,7 +30,7 @@ from .kernel_stream3d import kernel_name
 def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
          max_period=12, vgpr_budget=200, lds_budget=64 * 1024, split=2,
          waves_per_eu=3, loader=0, ring_prefetch=2, sched_fence=1, pairs=0,
-         xcd_remap=0, prio='3', xcd_tiles=1, buffer_io=1):
+         xcd_remap=0, prio='3', xcd_tiles=1, buffer_io=1, nt=0):
   """Returns (text, kernel table entry).
 
   split=2: the wavefront is a 32 x 2 grid of lanes; lane (lx, ly) holds columns
@@ -452,12 +453,20 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
           line('            if (!st_ragged) {')
           line('              const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_'
                'buffer_rsrc(q, 0, (int)plane_bytes, 0x27000);')
-          for r in range(R):
-            line('              { %s v;%s __builtin_amdgcn_raw_buffer_store_%s('
-                 '__builtin_bit_cast(%s, v), rs, (st_rows >> %d) & 1u ? lane_byte : '
-                 '0xfffffff0u, (unsigned)(%d * W * %d), 0); }' % (
-                     vec, ''.join(' v[%d] = %s;' % (c, out(r, c)) for c in range(C)),
-                     BUF_SUFFIX, BUF_TYPE, r, r, elem))
+          # nt = 4: launches whose box does not fit the Infinity Cache store around
+          # the caches (a wave-uniform branch next to the ones this store path has;
+          # kernel_common.NT_STREAMING_BYTES); 2: always
+          for aux in ((2, 0) if nt & 4 else (2,) if nt & 2 else (0,)):
+            if nt & 4:
+              line('              %s {' % ('if (st_streaming)' if aux else 'else'))
+            for r in range(R):
+              line('              { %s v;%s __builtin_amdgcn_raw_buffer_store_%s('
+                   '__builtin_bit_cast(%s, v), rs, (st_rows >> %d) & 1u ? lane_byte : '
+                   '0xfffffff0u, (unsigned)(%d * W * %d), %d); }' % (
+                       vec, ''.join(' v[%d] = %s;' % (c, out(r, c)) for c in range(C)),
+                       BUF_SUFFIX, BUF_TYPE, r, r, elem, aux))
+            if nt & 4:
+              line('              }')
           line('            } else {')
           for r in range(R):
             line('            if (%d >= st_r0 && %d < st_r1) {' % (r, r))
@@ -569,6 +578,10 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
       line('  unsigned st_rows = 0;')
       line('  for (int r = 0; r < %d; ++r) if (st_full && r >= st_r0 && r < st_r1) '
            'st_rows |= 1u << r;' % R)
+      if nt & 4:
+        line('  const bool st_streaming = (a.box_hi[0] - a.box_lo[0]) * (a.box_hi[1] - '
+             'a.box_lo[1]) * (a.box_hi[2] - a.box_lo[2]) * %d > %dll;' % (
+                 2 * elem, kernel_common.NT_STREAMING_BYTES))
       line('  const bool st_ragged = __builtin_amdgcn_ballot_w64(!st_full && (%s)) != 0;'
            % ' || '.join('st_col%d' % c for c in range(C)))
       line('  const i64 plane_bytes = W * H * %d; (void)plane_bytes; (void)st_rows; '
@@ -723,4 +736,6 @@ def emit(spec, depth, cols=2, rows=16, chunk_planes=64, prefetch=0, groups=4,
                groups=groups, lds_bytes=lds_bytes, split=split, loader=loader,
                pairs=pairs, xcd_tiles=4 * int(bool(xcd_tiles)), buffer_io=int(bool(buffer_io)),
                min_extent=[LX * C, TR] if split == 2 else [0, 0])
+  if nt and buffer_io and split == 2:
+    entry['nt'] = int(nt)
   return '\n'.join(o) + '\n', entry

@@ -197,6 +197,10 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   # their arithmetic as a hand-ordered instruction stream on top
   assert blk[0]['min_extent'] == [128, 64]
   assert (blk[0]['prefetch'], blk[0]['ring'], blk[0]['asm_sched']) == (0, 2, 0)
+  # launches beyond the Infinity Cache store around the caches: an instantiation of
+  # its own, chosen by the kernel's entry from the box it is given
+  assert blk[0]['nt'] == 4 and '_band<false, true>(' in text
+  assert '* 8 > %dll' % kernel_common.NT_STREAMING_BYTES in text
   in_registers = [k for k in kernel.generate(spec, blk_prefetch=1)[1] if k.get('stack')]
   assert (in_registers[0]['prefetch'], in_registers[0]['ring']) == (1, 0)
   assert blk[0]['xcd_tiles'] == -1 and blk[0]['fill_rows'] == 8
@@ -258,6 +262,33 @@ def test_3d_block_form_options_pairs_and_ring(tmp_path):
   from soda_hip.codegen import kernel_stream3d_blk
   _, entry = kernel_stream3d_blk.emit(spec_of('heat3d'), 4, stack=4, pairs=1)
   assert entry['pairs'] == 1
+
+
+def test_stores_around_the_caches_for_boxes_beyond_the_infinity_cache(tmp_path):
+  """The memory-bound kernels (2-D depth <= 2, 3-D single-wave, 3-D block form) carry
+  a second instantiation of their interior path whose stores are non-temporal, and
+  their entry takes it when the launch's box - all inputs and outputs - is larger
+  than kernel_common.NT_STREAMING_BYTES.  Deeper 2-D kernels and the 3-D
+  wave-pipelined form do not (measured: no gain)."""
+  limit = '%dll' % kernel_common.NT_STREAMING_BYTES
+  text, table = kernel.generate(spec_of('blur'))
+  assert [k.get('nontemporal') for k in table if k['kind'] == 'fused'] == [4]
+  assert '* 4 > ' + limit in text and '_strip<true, false, true>(' in text    # u16 in + out
+  text, table = kernel.generate(spec_of('denoise2d'))
+  assert '* 12 > ' + limit in text                  # two float inputs, one float output
+  text, table = kernel.generate(spec_of('jacobi2d', iterate=32))
+  by_depth = {k['depth']: k for k in table if k['kind'] == 'fused'}
+  assert by_depth[1].get('nontemporal') == 4 and by_depth[2].get('nontemporal') == 4
+  assert all('nontemporal' not in by_depth[d] and 'nt' not in by_depth[d]
+             for d in by_depth if d > 2)
+  text, table = kernel.generate(spec_of('denoise3d'))
+  assert [k.get('nt') for k in table if k['kind'] == 'fused'] == [4]
+  assert '_tile<true, true>(' in text and '* 12 > ' + limit in text
+  text, table = kernel.generate(spec_of('heat3d', iterate=8))
+  assert [k.get('nt') for k in table if k['depth'] == 4 and k.get('groups')] == [None]
+  # off on request
+  text, table = kernel.generate(spec_of('blur'), nontemporal=0)
+  assert 'nontemporal' not in text and limit not in text
 
 
 def test_lane_crossing_operands_leave_short_circuit_expressions():

@@ -192,6 +192,35 @@ def test_wave_pipelined_generator_forms(app, options):
     prog.blob.unload()
 
 
+@pytest.mark.parametrize('app,options,shape,iterate', [
+    ('blur', dict(nontemporal=2), (90, 1100), 1),
+    ('jacobi2d', dict(nontemporal=3), (77, 2100), 5),
+    ('sobel2d', dict(nontemporal=2), (130, 515), 1),
+    ('denoise3d', dict(nt=2), (40, 70, 300), 1),
+    ('jacobi3d', dict(nt=2, wp_nt=2, blk_nt=3), (30, 80, 260), 7),
+    ('heat3d', dict(nt=2, wp_nt=4, blk_nt=2), (33, 70, 140), 6)])
+def test_nontemporal_store_paths(app, options, shape, iterate):
+  """Stores (and loads) around the caches.  The shipped kernels take these paths
+  only for launches whose box is larger than the Infinity Cache (the full-size tests
+  below); forced on here, on small ragged arrays, they give the same bits."""
+  from soda_hip.codegen import kernel
+  spec = gpu_util.load_spec(app, iterate=iterate)
+  text, table = kernel.generate(spec, **options)
+  assert 'nontemporal' in text or ', 2); }' in text
+  prog = host.open_program(source=text, spec=spec)
+  try:
+    inputs = gpu_util.random_inputs(spec, shape)
+    got = prog.run_numpy(inputs, iterate=iterate)
+    orc = gpu_util.make_oracle(spec)
+    want = orc.run(inputs, iterate=iterate)
+    sl = orc.valid_slices(tuple(reversed(shape)), iterate)
+    for j, name in enumerate(spec['outputs']):
+      assert np.array_equal(got[j][sl], want[name][sl], equal_nan=True), (app, options)
+  finally:
+    prog.close()
+    prog.blob.unload()
+
+
 @pytest.mark.parametrize('shape', [
     (64, 64), (65, 257), (100, 241), (257, 1021), (41, 2049), (600, 97)])
 def test_jacobi2d_ragged_shapes(shape):
