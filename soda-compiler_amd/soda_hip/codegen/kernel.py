@@ -379,7 +379,8 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
               spec, depth, **common,
               **dict({'nontemporal': 4} if depth <= NT_AUTO_MAX_DEPTH_2D else {},
                      **{k: v for k, v in fused_options.items()
-                        if k not in WP_ONLY_OPTIONS and not k.startswith('k1_')}))
+                        if k not in WP_ONLY_OPTIONS and not k.startswith('k1_') and
+                        k != 'nt'}))
         except kernel_stream2d.NotFusable as e:
           notes.append('depth %d not fused: %s' % (depth, e))
       want_piped = piped is None and depth >= WAVE_PIPELINE_MIN_DEPTH and (
@@ -439,7 +440,8 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
             try:
               single = kernel_stream2d.emit(
                   spec, depth, **common,
-                  **{k: v for k, v in fused_options.items() if k not in WP_ONLY_OPTIONS})
+                  **{k: v for k, v in fused_options.items()
+                     if k not in WP_ONLY_OPTIONS and k != 'nt'})
             except kernel_stream2d.NotFusable as e2:
               notes.append('depth %d not fused: %s' % (depth, e2))
       if piped is None and single is None:
@@ -456,7 +458,7 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
       # rows per lane: as many as the register file allows (taller tiles waste
       # less on the y halo)
       options = {k: v for k, v in fused_options.items()
-                 if not k.startswith(('wp_', 'blk_')) and k != 'deep3d'}
+                 if not k.startswith(('wp_', 'blk_')) and k not in ('deep3d', 'nontemporal')}
       # (rows, columns) per lane: the tallest tile the register file allows (taller
       # tiles waste less on the y halo).  Programs with several live tensors
       # (denoise3d, lowered to g and output over the inputs f and u) fit with one
