@@ -134,7 +134,19 @@ def cpu_baseline(spec, dims, budget_s):
                          n, 'x'.join(map(str, dims)), n + 1, quota, logical, seconds))
 
 
-def measured_traffic(kernel, dims, iterate):
+def profile_entry_matches(entry, kernel, dims, iterate, digest, launches):
+  """A committed profile entry speaks for this run only if it was measured on the same
+  kernel (name AND shape digest, kernel.calibration_key), the same grid and iteration
+  count, and - per-launch averages depend on which launches of the sweep the kernel
+  got - about the same number of launches per sweep (one apart is tolerated: the
+  tuning step settles on neighbouring splits from run to run)."""
+  return entry['kernel'] == kernel and list(entry['dims']) == list(dims) and \
+      entry['iterate'] == iterate and entry.get('kernel_digest') == digest and \
+      digest is not None and \
+      abs(entry.get('launches', -99) - launches) <= max(1, launches // 20)
+
+
+def measured_traffic(kernel, dims, iterate, digest=None, launches=0):
   """HBM bytes per launch of `kernel` ON THIS GRID from the newest committed
   rocprofv3 PMC passes (profiles/rNN_traffic.json, written by
   tools/collect_profiles.py from separate --pmc runs of this same command: PMC
@@ -147,13 +159,12 @@ def measured_traffic(kernel, dims, iterate):
     with open(path) as f:
       data = json.load(f)
     for entry in data.get('entries', []):
-      if entry['kernel'] == kernel and list(entry['dims']) == list(dims) and \
-          entry['iterate'] == iterate:
+      if profile_entry_matches(entry, kernel, dims, iterate, digest, launches):
         return entry, os.path.basename(path)
   return None, None
 
 
-def measured_counters(kernel, dims, iterate):
+def measured_counters(kernel, dims, iterate, digest=None):
   """SQ counters of `kernel` on this grid from the newest committed PMC passes
   (profiles/rNN_sq_counters.json, tools/sq_counters.sh + collect_profiles.py):
   VALU issue utilisation and where a wavefront spends its life."""
@@ -164,7 +175,8 @@ def measured_counters(kernel, dims, iterate):
       data = json.load(f)
     for entry in data.get('entries', []):
       if entry['kernel'] == kernel and list(entry['dims']) == list(dims) and \
-          entry['iterate'] == iterate:
+          entry['iterate'] == iterate and digest is not None and \
+          entry.get('kernel_digest') == digest:
         return entry, os.path.basename(path)
   return None, None
 
@@ -234,7 +246,10 @@ def roofline_block(spec, program, schedule, updates, timing, dims, iterate,
   alg = upd * abytes / avg_s / 1e9
   ops = kernelmod.arithmetic_weight(spec)
   valu = upd * ops / avg_s / 1e12
-  traffic, source = measured_traffic(name, dims, iterate)
+  digest = ([kernelmod.calibration_key(e, spec) for e, _ in schedule if e['name'] == name]
+            or [None])[0]
+  traffic, source = measured_traffic(name, dims, iterate, digest,
+                                     timing['dominant_launches'])
   block = dict(kernel=name, kernel_avg_us=avg_s * 1e6, kernel_time_scale=scale,
                kernel_launches=timing['dominant_launches'],
                updates_per_launch=upd, algorithmic_bytes_per_update=abytes,
@@ -260,7 +275,7 @@ def roofline_block(spec, program, schedule, updates, timing, dims, iterate,
   # Which limit binds: with SQ counters for this kernel on this grid, the busier of
   # the two units (VALU issue utilisation against the share of the ACHIEVABLE HBM
   # rate); without, the larger fraction of peak.
-  sq, sq_source = measured_counters(name, dims, iterate)
+  sq, sq_source = measured_counters(name, dims, iterate, digest)
   valu_binds = block['valu_frac'] > hbm_frac
   if sq:
     block.update(valu_issue_utilisation=sq['valu_issue_utilisation'],

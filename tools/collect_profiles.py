@@ -10,8 +10,13 @@ tools/collect_on_gpu.sh) into the small files committed under profiles/:
 
 The traffic file holds one entry per (kernel, grid, iteration count): a figure
 measured on one grid says nothing about another, so bench.py only quotes an entry
-whose kernel AND dims AND iterate match its own run, and `commit` says which tree
-the kernels were built from.  FETCH_SIZE / WRITE_SIZE are in KiB.
+whose kernel AND dims AND iterate match its own run, whose `kernel_digest` (program +
+kernel shape, kernel.calibration_key) is that of the kernel it runs, and - a
+per-launch AVERAGE depends on which launches of the sweep went to that kernel - whose
+`launches` equals the number of launches the kernel has in its own sweep.  The
+averages are over the ONE timed sweep of the pass (the last `launches_per_step`
+dispatches), not over the sweeps the tuning step tried before it.  `commit` says which
+tree the kernels were built from.  FETCH_SIZE / WRITE_SIZE are in KiB.
 MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half the bytes of a
 coalesced streaming read, so it is doubled; WRITE_SIZE is exact.  The rule was
 re-checked for 4-, 8- and 16-byte-per-lane copies with tools/pmc_calib.hip
@@ -29,15 +34,47 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def counter_per_kernel(folder, counter):
+def counter_per_kernel(folder, counter, last=None):
+  """Counter values per kernel, in dispatch order; `last` = N keeps only the last N
+  dispatches of the run - the one timed sweep of `bench.py --steps 1`, not the sweeps
+  soda_hip_plan_tune tried before it (other splits, other kernels per launch)."""
   files = glob.glob(os.path.join(folder, '*', '*_counter_collection.csv'))
   if not files:
     return {}
+  rows = [r for r in csv.DictReader(open(max(files, key=os.path.getmtime)))
+          if r['Counter_Name'] == counter and not r['Kernel_Name'].startswith('__amd_rocclr')]
+  rows.sort(key=lambda r: int(r['Dispatch_Id']))
+  if last:
+    rows = rows[-last:]
   agg = collections.defaultdict(list)
-  for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
-    if r['Counter_Name'] == counter and not r['Kernel_Name'].startswith('__amd_rocclr'):
-      agg[r['Kernel_Name']].append(float(r['Counter_Value']))
+  for r in rows:
+    agg[r['Kernel_Name']].append(float(r['Counter_Value']))
   return agg
+
+
+def launches_per_step(log_path):
+  """config.launches_per_step of the bench line a PMC pass printed."""
+  try:
+    with open(log_path) as f:
+      for line in f:
+        if line.startswith('{"metric'):
+          return int(json.loads(line)['config']['launches_per_step'])
+  except (OSError, ValueError, KeyError):
+    pass
+  return None
+
+
+def kernel_digests(app):
+  """kernel name -> kernel.calibration_key of the kernels the shipped blob of `app`
+  is generated from (program + kernel shape): bench.py quotes a profile entry only for
+  the very kernel it was measured on."""
+  sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd')]
+  import __graft_entry__ as entry
+  from soda_hip import frontend
+  from soda_hip.codegen import kernel, spec as specmod
+  st = frontend.load(entry.sample_path(app), iterate=entry.BLOB_ITERATE.get(app))
+  spec = specmod.spec_from_stencil(st)
+  return {e['name']: kernel.calibration_key(e, spec) for e in kernel.generate(spec)[1]}
 
 
 def main():
@@ -69,16 +106,30 @@ def main():
       dims.append(int(words[i]))
       i += 1
     iterate = int(words[words.index('--iterate') + 1])
+    n_f = launches_per_step(os.path.join(src, 'pmc_%s_%s_FETCH_SIZE.log' % (tag, name)))
+    n_w = launches_per_step(os.path.join(src, 'pmc_%s_%s_WRITE_SIZE.log' % (tag, name)))
     fetch = counter_per_kernel(os.path.join(src, 'pmc_%s_%s_FETCH_SIZE' % (tag, name)),
-                               'FETCH_SIZE')
+                               'FETCH_SIZE', last=n_f)
     write = counter_per_kernel(os.path.join(src, 'pmc_%s_%s_WRITE_SIZE' % (tag, name)),
-                               'WRITE_SIZE')
+                               'WRITE_SIZE', last=n_w)
+    digests = kernel_digests(app)
     for kernel in sorted(set(fetch) & set(write)):
+      # (the tuning step may settle on a neighbouring split in the two passes - cfg4:
+      # 41x24+1x16 in one, 40x24+2x20 in the other; launches of one kernel differ little
+      # in size, so per-kernel averages from schedules one launch apart are kept)
+      if n_f is None or n_w is None or \
+          abs(len(fetch[kernel]) - len(write[kernel])) > max(1, len(fetch[kernel]) // 20):
+        print('%s %s: the two passes ran different schedules (%s / %s launches per step, '
+              '%d / %d of this kernel): skipped' % (
+                  name, kernel, n_f, n_w, len(fetch[kernel]), len(write[kernel])))
+        continue
       read_b = 2.0 * sum(fetch[kernel]) / len(fetch[kernel]) * 1024
       write_b = sum(write[kernel]) / len(write[kernel]) * 1024
       entries.append(dict(
           workload=name, app=app, kernel=kernel, dims=dims, iterate=iterate,
-          launches=len(fetch[kernel]), read_bytes_per_launch=read_b,
+          launches=len(fetch[kernel]), launches_write_pass=len(write[kernel]),
+          launches_per_step=n_f,
+          kernel_digest=digests.get(kernel), read_bytes_per_launch=read_b,
           write_bytes_per_launch=write_b, hbm_bytes_per_launch=read_b + write_b,
           read_over_write=read_b / write_b if write_b else None,
           fetch_size_raw_KiB=sum(fetch[kernel]) / len(fetch[kernel]),
@@ -100,13 +151,15 @@ def main():
     iterate = int(words[words.index('--iterate') + 1])
     with open(path) as f:
       summary = json.load(f)
+    app = words[words.index('--app') + 1]
+    digests = kernel_digests(app)
     for kernel, counters in sorted(summary.items()):
       derived = counters.get('_derived')
       if not derived or '_fused_' not in kernel and '_stage_' not in kernel:
         continue
       sq_entries.append(dict(
           workload=name, kernel=kernel, dims=dims, iterate=iterate, commit=commit,
-          launches=counters.get('_launches'),
+          launches=counters.get('_launches'), kernel_digest=digests.get(kernel),
           valu_instructions=counters.get('SQ_INSTS_VALU'),
           **{k: derived[k] for k in ('valu_issue_utilisation', 'valu_cycles_per_instruction',
                                      'wave_issuing', 'wave_issue_stalled', 'wave_parked',
