@@ -79,7 +79,8 @@ BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300, nt=4)
 # chunking): box 496 242 vs 247 us, 456 205 vs 219, 416 152 vs 166, 352 117 vs 130,
 # 256 53 vs 74; heat3d 512^3 x20, block form alone: 1.94 vs 1.96 ms, with the
 # arithmetic as a hand-ordered instruction stream (kernel_asm; pays for programs
-# above PACKED_3D_LIGHT_WEIGHT only) 1.83 vs 1.90 ms (profiles/r03_blk_variants.txt).
+# above PACKED_3D_LIGHT_WEIGHT only) 1.83 vs 1.90 ms (profiles/r03_blk_variants.txt);
+# packed pair-rows, which the ring's freed registers make room for, beat that.
 BLOCK_3D_RING_OPTIONS = dict(stack=8, prefetch=0, ring=2, vgpr_budget=300, nt=4)
 # ... for programs light enough on arithmetic: jacobi3d (weight 7) 417 us per
 # depth-4 launch against 2 x 374 us at depth 2, heat3d (15) 622 us against
@@ -496,13 +497,20 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
           # (kernel_stream3d_blk).  Named <app>_fused_k<d>b; with 'both' it ships
           # NEXT TO the wave-pipelined kernel and the run-time picks per launch
           given = prefixed_options(fused_options, 'blk_', kernel_stream3d_blk.emit)
+          heavy = arithmetic_weight(spec) > PACKED_3D_LIGHT_WEIGHT
+          ring_forms = [dict(BLOCK_3D_RING_OPTIONS, asm_sched=int(heavy))]
+          if heavy and kernel_stream2d_wp.packable(spec) and 'asm_sched' not in given:
+            # heavy plain-float programs: packed pair-rows first (heat3d 512^3 x20,
+            # block form alone, clocks warm: 1.76 ms plain, 1.49 hand-ordered, 1.42
+            # packed - 13.2 k instead of 22.6 k VALU instructions per unrolled loop,
+            # 254 VGPRs without spills now that the ring took the prefetch registers)
+            ring_forms.insert(0, dict(BLOCK_3D_RING_OPTIONS, pairs=1))
           attempts = [BLOCK_3D_OPTIONS] if 'prefetch' in given or 'ring' in given else \
-              [BLOCK_3D_RING_OPTIONS, BLOCK_3D_OPTIONS]
+              ring_forms + [BLOCK_3D_OPTIONS]
           try:
             for k, base in enumerate(attempts):
-              options = dict(base, asm_sched=int(
-                  base.get('ring', 0) > 0 and
-                  arithmetic_weight(spec) > PACKED_3D_LIGHT_WEIGHT))
+              options = dict(base)
+              options.setdefault('asm_sched', int(base.get('ring', 0) > 0 and heavy))
               options.update(given)
               try:
                 ftext, entry = kernel_stream3d_blk.emit(spec, depth, **options)

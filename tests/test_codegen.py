@@ -193,8 +193,7 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   # meet on 64-byte boundaries (origin_align 16 floats); XCD runs (xcd_tiles -1)
   assert blk[0]['block'] == [512, 1, 1] and blk[0]['tile'][:2] == [112, 56]
   assert blk[0]['origin_align'] == 16
-  # input planes through the two-slot LDS ring; heavier programs (heat3d below) get
-  # their arithmetic as a hand-ordered instruction stream on top
+  # input planes through the two-slot LDS ring
   assert blk[0]['min_extent'] == [128, 64]
   assert (blk[0]['prefetch'], blk[0]['ring'], blk[0]['asm_sched']) == (0, 2, 0)
   # launches beyond the Infinity Cache store around the caches: an instantiation of
@@ -222,8 +221,12 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   assert 'pk2_shifted{' in packed_text
   heat = kernel.generate(spec_of('heat3d', iterate=8))[1]
   assert [k.get('pairs') for k in heat if k['depth'] == 4 and k.get('groups')] == [1]
-  assert [(k['name'], k['ring'], k['asm_sched']) for k in heat if k.get('stack')] == [
-      ('heat3d_fused_k4b', 2, 1)]
+  # heavy plain-float programs: packed pair-rows in the block form too (the ring freed
+  # the registers for them); hand-ordered arithmetic when asked for / pairs refused
+  assert [(k['name'], k['ring'], k['pairs'], k['asm_sched']) for k in heat
+          if k.get('stack')] == [('heat3d_fused_k4b', 2, 1, 0)]
+  by_hand = kernel.generate(spec_of('heat3d', iterate=8), blk_pairs=0)[1]
+  assert [(k['pairs'], k['asm_sched']) for k in by_hand if k.get('stack')] == [(0, 1)]
   out = tmp_path / 'j3d.hsaco'
   kernel.compile_to_code_object(text, str(out))
   assert open(out, 'rb').read(4) == b'\x7fELF'
