@@ -139,11 +139,13 @@ def profile_entry_matches(entry, kernel, dims, iterate, digest, launches):
   kernel (name AND shape digest, kernel.calibration_key), the same grid and iteration
   count, and - per-launch averages depend on which launches of the sweep the kernel
   got - about the same number of launches per sweep (one apart is tolerated: the
-  tuning step settles on neighbouring splits from run to run)."""
+  tuning step settles on neighbouring splits from run to run), unless the entry's
+  launches were all of one size within 5 % (`uniform`: 2-D sweeps)."""
   return entry['kernel'] == kernel and list(entry['dims']) == list(dims) and \
       entry['iterate'] == iterate and entry.get('kernel_digest') == digest and \
-      digest is not None and \
-      abs(entry.get('launches', -99) - launches) <= max(1, launches // 20)
+      digest is not None and (
+          entry.get('uniform') or     # launches of (nearly) one size: any share will do
+          abs(entry.get('launches', -99) - launches) <= max(1, launches // 20))
 
 
 def measured_traffic(kernel, dims, iterate, digest=None, launches=0):

@@ -25,6 +25,8 @@ def test_profile_entries_match_only_their_own_kernel_and_schedule():
                      digest='p/k/d', launches=42), **kw))
   assert ok() and ok(launches=43) and ok(launches=41)
   assert not ok(launches=30)            # another share of the sweep's launches
+  assert bench.profile_entry_matches(dict(e, uniform=True), 'a_fused_k4b', (512, 512, 512),
+                                     200, 'p/k/d', 30)    # ... of equal-sized launches
   assert not ok(digest='p/k/other')     # the generator changed the kernel's shape
   assert not ok(digest=None)
   assert not ok(dims=(512, 512, 256)) and not ok(iterate=100) and not ok(kernel='a_fused_k4')

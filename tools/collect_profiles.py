@@ -117,8 +117,14 @@ def main():
       # (the tuning step may settle on a neighbouring split in the two passes - cfg4:
       # 41x24+1x16 in one, 40x24+2x20 in the other; launches of one kernel differ little
       # in size, so per-kernel averages from schedules one launch apart are kept)
-      if n_f is None or n_w is None or \
-          abs(len(fetch[kernel]) - len(write[kernel])) > max(1, len(fetch[kernel]) // 20):
+      # Launches whose counters agree within 5 % (2-D sweeps: the box shrinks by a
+      # few rows per launch) are `uniform`: their average does not depend on which
+      # launches of the sweep the kernel got, so a pass that tuned itself to another
+      # split still speaks for the kernel.
+      spread = max((max(v) - min(v)) / max(v) for v in (fetch[kernel], write[kernel]))
+      uniform = spread < 0.05
+      if n_f is None or n_w is None or (not uniform and abs(
+          len(fetch[kernel]) - len(write[kernel])) > max(1, len(fetch[kernel]) // 20)):
         print('%s %s: the two passes ran different schedules (%s / %s launches per step, '
               '%d / %d of this kernel): skipped' % (
                   name, kernel, n_f, n_w, len(fetch[kernel]), len(write[kernel])))
@@ -128,7 +134,7 @@ def main():
       entries.append(dict(
           workload=name, app=app, kernel=kernel, dims=dims, iterate=iterate,
           launches=len(fetch[kernel]), launches_write_pass=len(write[kernel]),
-          launches_per_step=n_f,
+          launches_per_step=n_f, uniform=uniform,
           kernel_digest=digests.get(kernel), read_bytes_per_launch=read_b,
           write_bytes_per_launch=write_b, hbm_bytes_per_launch=read_b + write_b,
           read_over_write=read_b / write_b if write_b else None,
