@@ -85,6 +85,7 @@ struct soda_hip_plan {
   // reach every CU (jacobi3d 128^3, depth 4: 67 us per launch with 32-plane
   // chunks)
   int chunk_rows_min = 8;
+  bool chunk_tie_short = false;      // SODA_HIP_CHUNK_TIE_SHORT, for tuning
   // soda_hip_plan_set_out_final_only: `out` is written by the LAST launch of a sweep
   // only; the launches before it alternate between scratch and scratch_b
   bool out_final_only = false;
@@ -341,7 +342,13 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
         const int64_t blocks = inner * ((extent + chunk - 1) / chunk);
         const int64_t rounds = (blocks + resident - 1) / resident;
         const int64_t cost = rounds * (chunk + desc.fill_rows);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = chunk; }
+        // among equal step counts the LONGEST chunk: fewer workgroups, fewer fill rows
+        // fetched (jacobi3d box 504^3: 5 chunks of 104 planes in one round and 11 of
+        // 48 in two both walk 112 steps; the long ones read 8 % less)
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && !plan->chunk_tie_short)) {
+          best_cost = cost;
+          best = chunk;
+        }
       }
       if (plan->chunk_rows_override > 0) best = plan->chunk_rows_override;
       tile = best;
@@ -1058,6 +1065,7 @@ int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* progra
     }
   }
   if (const char* env = tuning_env("SODA_HIP_CHUNK_ROWS")) pl->chunk_rows_override = atoi(env);
+  if (tuning_env("SODA_HIP_CHUNK_TIE_SHORT")) pl->chunk_tie_short = true;
   if (const char* env = tuning_env("SODA_HIP_CHUNK_MIN"))
     pl->chunk_rows_min = std::max(4, atoi(env));
   *plan = pl;
