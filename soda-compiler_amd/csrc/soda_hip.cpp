@@ -86,6 +86,7 @@ struct soda_hip_plan {
   // chunks)
   int chunk_rows_min = 8;
   bool chunk_tie_short = false;      // SODA_HIP_CHUNK_TIE_SHORT, for tuning
+  bool chunk_by_time = false;        // SODA_HIP_CHUNK_BY_TIME, for tuning
   // soda_hip_plan_set_out_final_only: `out` is written by the LAST launch of a sweep
   // only; the launches before it alternate between scratch and scratch_b
   bool out_final_only = false;
@@ -335,6 +336,16 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
       for (int e = 0; e < dim - 1; ++e) inner *= out->grid[e];
       const int64_t resident = std::max(1, plan->resident_blocks[k]);
       int64_t best = tile, best_cost = -1;
+      double best_time = -1;
+      double footprint = 0;      // bytes the launch streams: its box, in and out
+      {
+        double cells = 1;
+        for (int e = 0; e < dim; ++e) cells *= (double)(args.box_hi[e] - args.box_lo[e]);
+        const soda_hip_program& p = plan->prog;
+        for (int j = 0; j < p.n_inputs; ++j) footprint += cells * p.elem_size[j];
+        for (int j = 0; j < p.n_outputs; ++j)
+          footprint += cells * p.elem_size[p.output_tensor[j]];
+      }
       const int64_t shortest = plan->chunk_rows_min;   // 8; SODA_HIP_CHUNK_MIN
       for (int64_t chunk = shortest;
            chunk <= std::max<int64_t>(shortest, std::min<int64_t>(extent, 4096));
@@ -345,6 +356,20 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
         // among equal step counts the LONGEST chunk: fewer workgroups, fewer fill rows
         // fetched (jacobi3d box 504^3: 5 chunks of 104 planes in one round and 11 of
         // 48 in two both walk 112 steps; the long ones read 8 % less)
+        if (plan->chunk_by_time) {
+          // (tuning) the priced time instead of the step count: the step time depends
+          // on how many workgroups share a CU and, on arrays beyond the caches, on the
+          // bytes they move together
+          const double t = (double)cost * step_seconds(plan, k, (double)blocks, footprint);
+          if (t > 0) {
+            if (best_time < 0 || t < best_time * (1 - 1e-9) ||
+                (t <= best_time * (1 + 1e-9) && !plan->chunk_tie_short)) {
+              best_time = t;
+              best = chunk;
+            }
+            continue;
+          }
+        }
         if (best_cost < 0 || cost < best_cost || (cost == best_cost && !plan->chunk_tie_short)) {
           best_cost = cost;
           best = chunk;
@@ -355,15 +380,6 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
       out->args.param[0] = best;
       const double blocks = (double)inner * (double)((extent + best - 1) / best);
       const double rounds = std::ceil(blocks / (double)resident);
-      double footprint = 0;      // bytes the launch streams: its box, in and out
-      {
-        double cells = 1;
-        for (int e = 0; e < dim; ++e) cells *= (double)(args.box_hi[e] - args.box_lo[e]);
-        const soda_hip_program& p = plan->prog;
-        for (int j = 0; j < p.n_inputs; ++j) footprint += cells * p.elem_size[j];
-        for (int j = 0; j < p.n_outputs; ++j)
-          footprint += cells * p.elem_size[p.output_tensor[j]];
-      }
       out->est_us = kModelLaunchUs + rounds * (double)(best + desc.fill_rows) *
                                          step_seconds(plan, k, blocks, footprint) * 1e6;
     }
@@ -1066,6 +1082,7 @@ int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* progra
   }
   if (const char* env = tuning_env("SODA_HIP_CHUNK_ROWS")) pl->chunk_rows_override = atoi(env);
   if (tuning_env("SODA_HIP_CHUNK_TIE_SHORT")) pl->chunk_tie_short = true;
+  if (tuning_env("SODA_HIP_CHUNK_BY_TIME")) pl->chunk_by_time = true;
   if (const char* env = tuning_env("SODA_HIP_CHUNK_MIN"))
     pl->chunk_rows_min = std::max(4, atoi(env));
   *plan = pl;
