@@ -72,7 +72,7 @@ DEEP_3D_DEPTHS = (4,)
 # ms with either alone, 5.87 ms with the per-launch choice.  heat3d (packed pair-rows
 # in the wave-pipelined form): 392 vs 378 us per 512^3 launch.
 DEEP_3D_FORM = 'both'
-BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300, nt=4)
+BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300, nt=4, mask_loads=1)
 # The block form's input planes: through a two-slot LDS ring (LDS-direct loads, no
 # prefetch registers) where the program's edge rows leave the LDS for it, else one
 # plane ahead in registers.  Per depth-4 launch inside the 512^3 array of cfg5 (same
@@ -81,7 +81,11 @@ BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300, nt=4)
 # arithmetic as a hand-ordered instruction stream (kernel_asm; pays for programs
 # above PACKED_3D_LIGHT_WEIGHT only) 1.83 vs 1.90 ms (profiles/r03_blk_variants.txt);
 # packed pair-rows, which the ring's freed registers make room for, beat that.
-BLOCK_3D_RING_OPTIONS = dict(stack=8, prefetch=0, ring=2, vgpr_budget=300, nt=4)
+# mask_loads: ragged tiles fetch only what a stored cell depends on (the buffer form of the
+# LDS-direct load; cfg5 per launch: box 424 161 -> 157 us, 400 140 -> 135, 368 128 -> 120,
+# 360 118 -> 108; boxes that fill their tiles unchanged; the sweep -1.5 %)
+BLOCK_3D_RING_OPTIONS = dict(stack=8, prefetch=0, ring=2, vgpr_budget=300, nt=4,
+                             mask_loads=1)
 # ... for programs light enough on arithmetic: jacobi3d (weight 7) 417 us per
 # depth-4 launch against 2 x 374 us at depth 2, heat3d (15) 622 us against
 # 2 x 411 us; heavier programs are VALU-bound at depth 2 already

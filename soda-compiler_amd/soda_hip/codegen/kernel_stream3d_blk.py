@@ -377,7 +377,10 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   else:
     line('  const bool st_ragged = __builtin_amdgcn_ballot_w64(!st_full && (%s)) != 0;'
          % ' || '.join('st_col%d' % c for c in range(C)))
-  if mask_loads and not ring:
+  if mask_loads and ring:
+    line('  const i64 ld_rows = a.box_hi[1] + %d < H ? a.box_hi[1] + %d : H;' % (hi[1], hi[1]))
+    line('  const i64 ld_plane_bytes = ld_rows * W * %d;' % elem)
+  elif mask_loads:
     # a ragged tile reads only what some stored cell depends on: lanes right of the
     # box's reach "load" out of range (a loop-invariant offset), rows below it lie
     # past the record count of the plane's resource - neither costs an instruction
@@ -431,6 +434,20 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
 
   def ring_load(slot_index, plane_expr, indent):
     line(indent + '{ i64 zz = %s; if (zz > D - 1) zz = D - 1;' % plane_expr)
+    if mask_loads:
+      # the buffer form of the LDS-direct load: chunks right of the box's reach have an
+      # out-of-range offset, rows below it lie past the record count - neither is
+      # fetched (zeros arrive in the ring; only cells outside every stored cell's
+      # cone read them)
+      line(indent + '  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
+           'rsrc((void*)(g_in + zz * plane), 0, (int)ld_plane_bytes, 0x27000);')
+      for i in range(ring_loads):
+        line(indent + '  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__(('
+             'address_space(3))) void*)&in_ring[%d][wave][%d][0], 16, ld_dma_byte, '
+             '(unsigned)(%d * W * %d), 0, %d);' % (
+                 slot_index, i * rows_per_load, i * rows_per_load, elem, ld_aux))
+      line(indent + '}')
+      return
     line(indent + '  const %s* p = g_in + zz * plane + dma_lane;' % T)
     for i in range(ring_loads):
       line(indent + '  __builtin_amdgcn_global_load_lds((const __attribute__(('
@@ -445,6 +462,9 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     per_row = LANES * C * elem // 16
     line('  const i64 dma_lane = (y_band + lane / %d) * W + wx + (lane %% %d) * %d;'
          % (per_row, per_row, 16 // elem))
+    if mask_loads:
+      line('  const unsigned ld_dma_byte = wx + (lane %% %d) * %d < a.box_hi[0] + %d ? '
+           '(unsigned)(dma_lane * %d) : 0xfffffff0u;' % (per_row, 16 // elem, hi[0], elem))
     for k in range(ring):
       ring_load(k, 'head + %d' % k, '  ')
     # the first planes are waited for outright; from step `ring` on the counted
@@ -806,6 +826,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
                min_extent=[LANES * C, TR])
   if nt:                    # (only when set: the shipped kernels' calibration keys stay)
     entry['nt'] = int(nt)
-  if mask_loads and not ring:
+  if mask_loads:
     entry['mask_loads'] = 1
   return '\n'.join(o) + '\n', entry

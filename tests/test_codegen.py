@@ -253,7 +253,12 @@ def test_3d_block_form_options_pairs_and_ring(tmp_path):
   body = text[text.index('jacobi3d_fused_k4b_band('):]
   # one plane of ring loads (4 x 2 rows) and 2 steps x 8 stores behind the awaited one
   # (the instantiation for ragged tiles stores column by column: 2 x 8 x 2 stores)
-  assert '// vmcnt(36 / 20)' in body and '__builtin_amdgcn_global_load_lds' in body
+  # (the shipped ring loads are the buffer form, masked to the box's reach; the plain
+  # global form with blk_mask_loads=0)
+  assert '// vmcnt(36 / 20)' in body and '__builtin_amdgcn_raw_ptr_buffer_load_lds' in body
+  assert 'ld_dma_byte' in body and '__builtin_amdgcn_global_load_lds' not in body
+  plain = kernel.generate(spec, depths=[4], deep3d='blk', blk_mask_loads=0)[0]
+  assert '__builtin_amdgcn_global_load_lds' in plain and 'ld_dma_byte' not in plain
   assert 'soda_lds_barrier();' in body and 'soda_block_barrier();' not in body
   assert 'pk2_shifted{' in body and 'pk_from_lane_below(' in body
   assert 'if (z >= z0 && z < z1) {' not in body       # stores are never skipped
