@@ -95,7 +95,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
          max_period=12, vgpr_budget=250, waves_per_eu=0, xcd_tiles=1, ring=0,
          pairs=0, align_out=16, xcd_runs=1, stamps=0,
          flat_stores=2, skip_fill=0, fence=1, asm_sched=0, asm_group=4,
-         edge_ahead=1, mask_loads=0, nt=0):
+         edge_ahead=1, mask_loads=0, nt=0, skip_bands=0):
   """Returns (text, kernel table entry).
 
   `prefetch` = input planes loaded ahead into REGISTERS (R*C VGPRs each);
@@ -781,6 +781,13 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('  i64 wy = yb;')
   line('  if (wy + %d > a.dims[1]) wy = a.dims[1] - %d;' % (TR, TR))
   line('  if (wy < 0) wy = 0;')
+  if skip_bands:
+    # a band whose rows lie outside every stored cell's dependency cone (ragged tiles at
+    # the box's y edges) has nothing to do: its wavefront leaves - the hardware takes
+    # ended wavefronts out of the barrier count - and the SIMD is its partner's alone.
+    # What it would have published is read only by cells outside the cone as well.
+    line('  if (wy + wave * %d >= a.box_hi[1] + %d || wy + (wave + 1) * %d <= a.box_lo[1] - %d) '
+         'return;' % (R, hi[1], R, lo[1]))
   if flat_stores == 2:
     # does any lane of this tile store only some of its columns?  (tiles at the box's
     # x edges when the box does not start or end on a lane boundary)
@@ -828,4 +835,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     entry['nt'] = int(nt)
   if mask_loads:
     entry['mask_loads'] = 1
+  if skip_bands:
+    entry['skip_bands'] = 1
   return '\n'.join(o) + '\n', entry
