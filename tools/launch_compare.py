@@ -18,9 +18,11 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
   opts = {k: ([int(x) for x in v.split('/')] if '/' in v else
               int(v) if v.lstrip('-').isdigit() else v)
           for k, v in (kv.split('=', 1) for kv in variant.split(',') if kv)}
+  # flags=-mllvm:-amdgpu-sched-strategy=iterative-ilp  -> extra hipcc flags
+  flags = opts.pop('flags', '').split(':') if opts.get('flags') else []
   text, _ = kernel.generate(spec, **opts)
   path = '/tmp/lc_%d.hsaco' % os.getpid()
-  kernel.compile_to_code_object(text, path)
+  kernel.compile_to_code_object(text, path, extra_flags=flags)
   prog = host.open_program(blob=path, spec=spec)
   shape = (n,) * spec['dim']
   if os.environ.get('LC_WARM'):
