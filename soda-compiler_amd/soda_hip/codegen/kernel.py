@@ -72,7 +72,8 @@ DEEP_3D_DEPTHS = (4,)
 # ms with either alone, 5.87 ms with the per-launch choice.  heat3d (packed pair-rows
 # in the wave-pipelined form): 392 vs 378 us per 512^3 launch.
 DEEP_3D_FORM = 'both'
-BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300, nt=4, mask_loads=1)
+BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300, nt=4, mask_loads=1,
+                        wide_stores=2)
 # The block form's input planes: through a two-slot LDS ring (LDS-direct loads, no
 # prefetch registers) where the program's edge rows leave the LDS for it, else one
 # plane ahead in registers.  Per depth-4 launch inside the 512^3 array of cfg5 (same
@@ -84,8 +85,12 @@ BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300, nt=4, mask_loads=1
 # mask_loads: ragged tiles fetch only what a stored cell depends on (the buffer form of the
 # LDS-direct load; cfg5 per launch: box 424 161 -> 157 us, 400 140 -> 135, 368 128 -> 120,
 # 360 118 -> 108; boxes that fill their tiles unchanged; the sweep -1.5 %)
+# wide_stores: row segments leave in whole 64-byte pieces - the cells between the box
+# and the next 64-byte boundary (unspecified by contract, read by nobody) are stored
+# along, in launches beyond the Infinity Cache (2; 1 = always: boxes of 232^3 .. 336^3
+# +1 %): cfg5 with this form alone 4.95 -> 4.79 ms, box 496 225 -> 210 us, 440 172 -> 156
 BLOCK_3D_RING_OPTIONS = dict(stack=8, prefetch=0, ring=2, vgpr_budget=300, nt=4,
-                             mask_loads=1)
+                             mask_loads=1, wide_stores=2)
 # ... for programs light enough on arithmetic: jacobi3d (weight 7) 417 us per
 # depth-4 launch against 2 x 374 us at depth 2, heat3d (15) 622 us against
 # 2 x 411 us; heavier programs are VALU-bound at depth 2 already
@@ -508,7 +513,9 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
             # block form alone, clocks warm: 1.76 ms plain, 1.49 hand-ordered, 1.42
             # packed - 13.2 k instead of 22.6 k VALU instructions per unrolled loop,
             # 254 VGPRs without spills now that the ring took the prefetch registers)
-            ring_forms.insert(0, dict(BLOCK_3D_RING_OPTIONS, pairs=1))
+            # (and exact store ranges: whole 64-byte pieces cost this kernel 3 %,
+            # heat3d 512^3 x20 1.37 -> 1.41 ms, where they gain jacobi3d's 2 %)
+            ring_forms.insert(0, dict(BLOCK_3D_RING_OPTIONS, pairs=1, wide_stores=0))
           attempts = [BLOCK_3D_OPTIONS] if 'prefetch' in given or 'ring' in given else \
               ring_forms + [BLOCK_3D_OPTIONS]
           try:

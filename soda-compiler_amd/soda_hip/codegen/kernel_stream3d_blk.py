@@ -95,7 +95,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
          max_period=12, vgpr_budget=250, waves_per_eu=0, xcd_tiles=1, ring=0,
          pairs=0, align_out=16, xcd_runs=1, stamps=0,
          flat_stores=2, skip_fill=0, fence=1, asm_sched=0, asm_group=4,
-         edge_ahead=1, mask_loads=0, nt=0, skip_bands=0):
+         edge_ahead=1, mask_loads=0, nt=0, skip_bands=0, wide_stores=0):
   """Returns (text, kernel table entry).
 
   `prefetch` = input planes loaded ahead into REGISTERS (R*C VGPRs each);
@@ -338,6 +338,33 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
       line('  ' + ' '.join('v%d_%d = t%d[%d];' % (r, c, r, c) for c in range(C)))
     line('}')
   nt_auto = bool(nt & 4) and flat_stores == 2
+  stream_expr = ('(a.box_hi[0] - a.box_lo[0]) * (a.box_hi[1] - a.box_lo[1]) * '
+                 '(a.box_hi[2] - a.box_lo[2]) * %d > %dll' % (
+                     2 * elem, kernel_common.NT_STREAMING_BYTES))
+  if wide_stores and align_out * elem % 64 == 0:
+    # Row segments are stored in whole 64-byte pieces: the columns between the box and
+    # the next 64-byte boundary on either side get the tile's values for them too.  They
+    # lie outside the valid box of this level - unspecified cells by contract
+    # (include/soda_hip.h: soda_hip_sweep), which no later launch reads: its box plus
+    # reach is this box - and no other tile stores them.  A box that starts 16 bytes
+    # into a line otherwise costs its edge tiles masked partial writes (4.1d).
+    # wide_stores = 2: only for launches beyond the Infinity Cache (the non-temporal
+    # instantiation; inside the caches a partial line costs nothing and the extra cells
+    # are only more bytes: boxes of 232^3 .. 336^3 +1 %)
+    seg = 64 // elem
+    when = 'ST_WIDE' if wide_stores == 2 else None
+    store_range = [
+        '  i64 st_box_lo = a.box_lo[0], st_box_hi = a.box_hi[0];',
+        '  %s{ st_box_lo -= st_box_lo %% %d; st_box_hi += %d - 1; st_box_hi -= st_box_hi %% %d; '
+        'if (st_box_hi > a.dims[0]) st_box_hi = a.dims[0]; }' % (
+            'if (%s) ' % when if when else '', seg, seg, seg),
+        '  const i64 st_lo = xs > st_box_lo ? xs : st_box_lo;',
+        '  const i64 st_hi = xs + %d < st_box_hi ? xs + %d : st_box_hi;' % (w_out, w_out)]
+  else:
+    wide_stores = 0
+    store_range = [
+        '  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];',
+        '  const i64 st_hi = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];' % (w_out, w_out)]
   if flat_stores == 2:
     line('template <bool RAGGED%s>' % (', bool NT' if nt_auto else ''))
   line('DEV void %s_band(const soda_hip_args& a, const i64 xs, const i64 yb, '
@@ -351,9 +378,10 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('  const i64 x = wx + lane * %d;' % C)
   line('  const i64 y_band = wy + wave * %d;     // first row of this band' % R)
   line('  const unsigned lane_byte = (unsigned)((y_band * W + x) * %d);' % elem)
-  line('  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];')
-  line('  const i64 st_hi = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];'
-       % (w_out, w_out))
+  if wide_stores == 2:
+    line('  const bool ST_WIDE = %s;' % ('NT' if nt_auto else stream_expr))
+  for text in store_range:
+    line(text)
   line('  const i64 st_ylo = a.box_lo[1] > yb + %d ? a.box_lo[1] : yb + %d;'
        % (y_lo, y_lo))
   line('  const i64 st_yhi = a.box_hi[1] < yb + %d ? a.box_hi[1] : yb + %d;'
@@ -792,9 +820,11 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     # does any lane of this tile store only some of its columns?  (tiles at the box's
     # x edges when the box does not start or end on a lane boundary)
     line('  const i64 x = wx + lane * %d;' % C)
-    line('  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];')
-    line('  const i64 st_hi = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];'
-         % (w_out, w_out))
+    if nt_auto or wide_stores == 2:
+      line('  const bool streaming = %s;' % stream_expr)
+      line('  const bool ST_WIDE = streaming; (void)ST_WIDE;')
+    for text in store_range:
+      line(text)
     line('  const bool partial = !(x >= st_lo && x + %d <= st_hi) && (%s);' % (
         C, ' || '.join('(x + %d >= st_lo && x + %d < st_hi)' % (c, c) for c in range(C))))
     call = '%s_band<%%s>(a, xs, yb, wx, wy, z0, z1, wave, lane, edges, %s);' % (
@@ -804,9 +834,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
       # (kernel_common.NT_STREAMING_BYTES; jacobi3d per launch inside a 512^3 array,
       # always / never: box 496 222 vs 246 us, 448 161 vs 176, 400 141 vs 153, 344 106
       # vs 111, 320 85 vs 81, 224 46 vs 40, 112 35 vs 35)
-      line('  const bool streaming = (a.box_hi[0] - a.box_lo[0]) * (a.box_hi[1] - '
-           'a.box_lo[1]) * (a.box_hi[2] - a.box_lo[2]) * %d > %dll;' % (
-               2 * elem, kernel_common.NT_STREAMING_BYTES))
       line('  const bool ragged = __builtin_amdgcn_ballot_w64(partial) != 0;')
       line('  if (streaming) { if (ragged) %s else %s }' % (call % 'true, true',
                                                            call % 'false, true'))
@@ -837,4 +864,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     entry['mask_loads'] = 1
   if skip_bands:
     entry['skip_bands'] = 1
+  if wide_stores:
+    entry['wide_stores'] = int(wide_stores)
   return '\n'.join(o) + '\n', entry

@@ -199,6 +199,9 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   # launches beyond the Infinity Cache store around the caches: an instantiation of
   # its own, chosen by the kernel's entry from the box it is given
   assert blk[0]['nt'] == 4 and '_band<false, true>(' in text
+  # ... and in whole 64-byte pieces: the cells between the box and the next boundary
+  # are unspecified by contract (include/soda_hip.h) and stored along
+  assert blk[0]['wide_stores'] == 2 and 'const bool ST_WIDE = NT;' in text
   assert '* 8 > %dll' % kernel_common.NT_STREAMING_BYTES in text
   in_registers = [k for k in kernel.generate(spec, blk_prefetch=1)[1] if k.get('stack')]
   assert (in_registers[0]['prefetch'], in_registers[0]['ring']) == (1, 0)

@@ -301,6 +301,11 @@ def test_3d_wave_pipelined_forms_on_heat3d(options):
     ('heat3d', dict(deep3d='blk', blk_pairs=0)),           # ring + hand-ordered arithmetic
     ('jacobi3d', dict(deep3d='blk', blk_mask_loads=0)),    # unmasked global_load_lds ring
     ('jacobi3d', dict(deep3d='blk', blk_skip_bands=1)),    # idle bands of ragged tiles leave
+    # row segments stored in whole 64-byte pieces (shipped: only in launches beyond the
+    # Infinity Cache - the full-size tests; forced on here), and never
+    ('jacobi3d', dict(deep3d='blk', blk_wide_stores=1)),
+    ('heat3d', dict(deep3d='blk', blk_wide_stores=1, blk_nt=2)),
+    ('jacobi3d', dict(deep3d='blk', blk_wide_stores=0)),
     ('jacobi3d', dict(deep3d='blk', blk_prefetch=1, blk_mask_loads=0)),
     ('jacobi3d', dict(deep3d='blk', blk_stack=4, blk_prefetch=0)),
     ('jacobi3d', dict(deep3d='blk', blk_stack=8, blk_rows=4, blk_prefetch=2)),
