@@ -234,7 +234,10 @@ typedef struct soda_hip_timing {
 /* The device sweep: `iterate` applications of the program on device arrays.
  *   in[j]   level-0 arrays, never written
  *   out[j]  receive level `iterate`; cells outside the valid box are
- *           unspecified (the reference leaves them unspecified too)
+ *           unspecified (the reference leaves them unspecified too) and MAY BE
+ *           WRITTEN: launches ping-pong through out[j], and a kernel may store the
+ *           cells between the box and the next 64-byte boundary of a row along
+ *           (whole-line writes); nothing outside the array is ever touched
  *   valid_lo/valid_hi  NULL, or per-dimension margins of the region of `in`
  *           that holds defined data: [valid_lo[d], dims[d] - valid_hi[d]).
  *           NULL means the whole array (a fresh run).  A caller that resumes
