@@ -125,18 +125,18 @@ def geometry(spec, depth, cols, chunk_rows, align='none'):
   line -= line % cols
   halo_lo = -(-lo[0] // cols) * cols      # padded up to whole vectors
   halo_hi = -(-hi[0] // cols) * cols
-  if align == 'store64':     # ... on a 64-byte piece (what a partial write is counted in)
-    line = max(cols, 64 // elem)
+  if align in ('store64', 'full64'):   # ... on a 64-byte piece (what a partial write
+    line = max(cols, 64 // elem)       # is counted in)
     line -= line % cols
-  if align == 'full':
+  if align in ('full', 'full64'):
     halo_lo = -(-lo[0] // line) * line
   w_out = LANES * cols - halo_lo - halo_hi
   origin_align = cols
-  if align in ('store', 'store64', 'full') and w_out >= line:
+  if align in ('store', 'store64', 'full', 'full64') and w_out >= line:
     w_out -= w_out % line
     halo_hi = LANES * cols - halo_lo - w_out
     origin_align = line
-  elif align not in ('none', 'store', 'store64', 'full'):
+  elif align not in ('none', 'store', 'store64', 'full', 'full64'):
     raise ValueError('align: %r' % (align,))
   if w_out < cols:
     raise NotFusable('depth %d leaves no output columns in a strip' % depth)
