@@ -63,6 +63,11 @@ def parse_args():
                   help='split `iterate` into fused depths by the calibrated model alone '
                        'instead of timing the candidate splits on this grid during '
                        'warm-up (soda_hip_plan_tune)')
+  ap.add_argument('--split', default='',
+                  help="the split of `iterate` into fused depths, fixed: '41x24+1x16' as "
+                       'config.depth_schedule of an earlier run prints it (profiling '
+                       'passes repeat the schedule of the timed run with it); implies '
+                       '--no-tune (soda_hip_plan_set_split)')
   ap.add_argument('--jit', action='store_true',
                   help='compile the kernels with hiprtc instead of loading the '
                        'code object built by __graft_entry__.build()')
@@ -323,6 +328,13 @@ def run_single(args):
   ip, op = [d.ptr for d in din], [d.ptr for d in dout]
   sync = torch.cuda.synchronize if torch.cuda.is_available() else \
       (lambda: host.capi.check(host.capi.lib().soda_hip_stream_synchronize(None)))
+  if args.split:
+    depths = []
+    for part in args.split.split('+'):
+      count, _, depth = part.partition('x')
+      depths += [int(depth)] * int(count)
+    program.set_split(dims, args.iterate, depths)
+    args.no_tune = True
   for _ in range(args.warmup):
     program.sweep(ip, op, dims, args.iterate)
   sync()
@@ -360,7 +372,8 @@ def run_single(args):
                   nominal_gcell_updates_per_s=nominal / (wall / args.steps) / 1e9,
                   launches_per_step=timing['launches'],
                   depth_schedule=schedule_text(schedule),
-                  depth_split='measured (soda_hip_plan_tune)' if not args.no_tune and
+                  depth_split='given (--split)' if args.split else
+                  'measured (soda_hip_plan_tune)' if not args.no_tune and
                   args.iterate > 1 else 'calibrated model',
                   effective_GBps=valid * abytes / (wall / args.steps) / 1e9,
                   device=host.device_info(0)['arch']),

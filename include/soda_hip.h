@@ -290,6 +290,15 @@ int soda_hip_plan_tune(soda_hip_plan* plan, void* const* in, void* const* out,
                        const int64_t dims[SODA_HIP_MAX_DIMS], int iterate,
                        const int32_t* valid_lo, const int32_t* valid_hi, void* stream);
 
+/* Fixes the split of `iterate` into fused depths for arrays of these extents (what
+ * soda_hip_plan_tune finds by measurement): depths[0..n) in launch order, each the depth
+ * of a fused kernel of the blob, adding up to `iterate`; n = 0 gives the choice back to
+ * the scheduler.  Profiling passes use it to repeat the schedule of an earlier run
+ * (bench.py --split).  Same-depth kernels are still chosen per launch; a kernel the
+ * array is too small for makes the schedule fall back to the scheduler's own. */
+int soda_hip_plan_set_split(soda_hip_plan* plan, const int64_t dims[SODA_HIP_MAX_DIMS],
+                            int iterate, const int32_t* depths, int n_depths);
+
 /* on != 0: a sweep writes `out` with its LAST launch only; the launches before it
  * alternate between two plan-owned arrays (the second one is allocated when a sweep
  * first needs it).  By default the intermediate launches alternate between one

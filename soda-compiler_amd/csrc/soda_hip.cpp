@@ -1190,6 +1190,34 @@ int soda_hip_plan_tune(soda_hip_plan* plan, void* const* in, void* const* out,
   return rc;
 }
 
+int soda_hip_plan_set_split(soda_hip_plan* plan, const int64_t dims[SODA_HIP_MAX_DIMS],
+                            int iterate, const int32_t* depths, int n_depths) {
+  if (!plan || !dims) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  const soda_hip_program& p = plan->prog;
+  std::array<int64_t, 5> key;
+  for (int d = 0; d < 4; ++d) key[d] = d < p.dim ? dims[d] : 1;
+  key[4] = iterate;
+  if (!depths || n_depths <= 0) {      // back to the scheduler's own choice
+    plan->tuned_split.erase(key);
+    return 0;
+  }
+  int total = 0;
+  for (int i = 0; i < n_depths; ++i) {
+    bool known = false;
+    for (const soda_hip_kernel& kd : plan->kernels)
+      known = known || (kd.kind == SODA_HIP_KERNEL_FUSED && kd.depth == depths[i]);
+    if (!known)
+      return fail(SODA_HIP_ERR_NO_KERNEL, "no fused kernel of depth %d in the blob",
+                  (int)depths[i]);
+    total += depths[i];
+  }
+  if (total != iterate)
+    return fail(SODA_HIP_ERR_CONSTRAINT, "the depths add up to %d, not to iterate = %d",
+                total, iterate);
+  plan->tuned_split[key] = std::vector<int>(depths, depths + n_depths);
+  return 0;
+}
+
 int soda_hip_plan_set_out_final_only(soda_hip_plan* plan, int on) {
   if (!plan) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "plan is NULL");
   plan->out_final_only = on != 0;

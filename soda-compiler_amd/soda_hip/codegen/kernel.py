@@ -364,14 +364,13 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
                     chunk_rows=chunk_rows or 256,
                     prefetch=3 if prefetch is None else prefetch)
       if 'align' not in fused_options:
-        # deeper: strips that start and end on 64-byte pieces (the unit a partial
-        # write is counted in) whatever the box's corner - jacobi2d depth 20 keeps 464
-        # of its 472 columns and cfg2 goes from 0.952 to 0.920 ms, cfg4 (464 wide
-        # anyway, but starting 32 bytes into a piece in every other launch) -0.9 %,
-        # seidel2d unchanged (profiles/r03_blk_variants.txt)
+        # (deeper kernels keep the widest strips: strips on 64-byte pieces,
+        # align='store64', gain 1.8 % on cfg2 in short runs and LOSE 1.3 % under the
+        # bench protocol's sustained load - 0.949 vs 0.961 ms, three alternating pairs
+        # in one call; cfg4 29.17 vs 29.22 ms)
         common['align'] = 'full' if (
             depth <= ALIGN_FULL_MAX_DEPTH and
-            arithmetic_weight(spec) <= ALIGN_FULL_MAX_WEIGHT) else 'store64'
+            arithmetic_weight(spec) <= ALIGN_FULL_MAX_WEIGHT) else 'none'
       single = piped = None
       k1 = {k[3:]: v for k, v in fused_options.items() if k.startswith('k1_')}
       if depth == 1 and k1.get('ring'):

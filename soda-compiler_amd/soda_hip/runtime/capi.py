@@ -120,6 +120,8 @@ SIGNATURES = {
     'soda_hip_plan_set_out_final_only': (ctypes.c_int, [_VP, ctypes.c_int]),
     'soda_hip_plan_tune': (ctypes.c_int, [_VP, _VPP, _VPP, _I64P, ctypes.c_int, _I32P,
                                           _I32P, _VP]),
+    'soda_hip_plan_set_split': (ctypes.c_int, [_VP, _I64P, ctypes.c_int, _I32P,
+                                               ctypes.c_int]),
     'soda_hip_sweep': (ctypes.c_int, [_VP, _VPP, _VPP, _I64P, ctypes.c_int, _I32P,
                                       _I32P, _VP]),
     'soda_hip_sweep_timed': (ctypes.c_int, [_VP, _VPP, _VPP, _I64P, ctypes.c_int,

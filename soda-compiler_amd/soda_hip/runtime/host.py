@@ -280,6 +280,15 @@ class Program:
         self.handle, self._ptr_array(in_ptrs), self._ptr_array(out_ptrs),
         self._dims(dims), iterate, vlo, vhi, stream))
 
+  def set_split(self, dims, iterate, depths):
+    """Fixes the split of `iterate` into fused depths for these extents, in launch
+    order; an empty list gives the choice back to the scheduler
+    (soda_hip_plan_set_split)."""
+    depths = list(depths or [])
+    arr = (ctypes.c_int32 * max(1, len(depths)))(*depths)
+    capi.check(capi.lib().soda_hip_plan_set_split(
+        self.handle, self._dims(dims), iterate, arr, len(depths)))
+
   def schedule(self, dims, iterate, valid_lo=None, valid_hi=None):
     """The launches `sweep` would issue: [(kernel table entry, modelled us)]."""
     vlo = vhi = None

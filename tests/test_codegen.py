@@ -159,20 +159,19 @@ def test_default_depth_sets():
   fused = {k['depth']: k for k in table if k['kind'] == 'fused'}
   assert sorted(fused) == [1, 2, 4, 8, 12, 16, 20, 24]
   assert all(k['step_valu'] > 0 and k['step_bytes'] > 0 for k in fused.values())
-  # strips of the deep kernels start and end on 64-byte pieces: 464 = 29 x 16 columns
-  # at depth 24 anyway, 464 of the 472 the halo would allow at depth 20
-  assert fused[24]['tile'][0] == 464 and fused[20]['tile'][0] == 464
-  assert fused[24]['origin_align'] == 16 and fused[2]['origin_align'] == 32
-  loose = {k['depth']: k for k in kernel.generate(spec_of('jacobi2d', iterate=1000),
-                                                  align='none')[1] if k['kind'] == 'fused'}
-  assert loose[20]['tile'][0] == 472 and loose[20]['origin_align'] == 4
+  assert fused[24]['tile'][0] == 464 and fused[20]['tile'][0] == 472
+  # (strips on 64-byte pieces are an option: measured, slower under sustained load)
+  assert fused[24]['origin_align'] == 4 and fused[2]['origin_align'] == 32
+  pieces = {k['depth']: k for k in kernel.generate(spec_of('jacobi2d', iterate=1000),
+                                                   align='store64')[1] if k['kind'] == 'fused'}
+  assert pieces[20]['tile'][0] == 464 and pieces[20]['origin_align'] == 16
   assert fused[24]['fill_rows'] == 51
   assert fused[12]['groups'] == 4 and fused[12]['pairs'] and not fused[8].get('groups')
   k16 = fused[16]
   # wide strips (512 columns per wavefront), 12-slot ring, four workgroups per CU
   assert k16['groups'] == 4 and k16['pairs'] == 2 and k16['ring'] == 12
   assert k16['min_extent'] == [512, 1] and k16['block'] == [256, 1, 1]
-  assert k16['tile'][0] == 480 and fused[12]['ring'] == 6 and fused[12]['tile'][0] == 480
+  assert k16['tile'][0] == 480 and fused[12]['ring'] == 6
   table = kernel.generate(spec_of('jacobi2d', iterate=15))[1]
   assert max(k['depth'] for k in table) == 12
   table = kernel.generate(spec_of('seidel2d', iterate=100))[1]

@@ -1090,6 +1090,7 @@ def test_tuned_split_changes_speed_only(app, shape, iterate):
   """soda_hip_plan_tune runs the candidate splits of `iterate` as whole sweeps and
   keeps the fastest for these extents: the schedule afterwards still adds up to
   `iterate`, the result is still the oracle's, and other extents are unaffected."""
+  from soda_hip.runtime import capi
   spec = gpu_util.load_spec(app)
   prog = gpu_util.open_prebuilt(app)      # a plan of its own: tuning is plan state
   try:
@@ -1111,6 +1112,23 @@ def test_tuned_split_changes_speed_only(app, shape, iterate):
     want = orc.run([a], iterate=iterate)[spec['outputs'][0]]
     sl = orc.valid_slices(tuple(dims), iterate)
     assert want[sl].size > 0 and np.array_equal(got[sl], want[sl])
+    # a GIVEN split (soda_hip_plan_set_split: what profiling passes repeat a timed
+    # run's schedule with): used as given, same result; rejected when it does not
+    # add up or names a depth the blob has no kernel of; an empty one gives the
+    # choice back to the scheduler
+    given = [1] * (iterate % 2) + [2] * (iterate // 2)
+    prog.set_split(dims, iterate, given)
+    assert [k['depth'] for k, _ in prog.schedule(dims, iterate)] == given
+    dout.zero()
+    prog.sweep([din.ptr], [dout.ptr], dims, iterate)
+    assert np.array_equal(dout.download(a.shape, a.dtype)[sl], want[sl])
+    with pytest.raises(capi.SodaHipError, match='add up'):
+      prog.set_split(dims, iterate, [2] * (iterate // 2 + 1))
+    with pytest.raises(capi.SodaHipError, match='no fused kernel of depth 7'):
+      prog.set_split(dims, iterate, [7])
+    prog.set_split(dims, iterate, [])
+    assert sum(k['depth'] for k, _ in prog.schedule(dims, iterate)) == iterate
+    assert max(k['depth'] for k, _ in prog.schedule(dims, iterate)) > 2
     din.free()
     dout.free()
   finally:
