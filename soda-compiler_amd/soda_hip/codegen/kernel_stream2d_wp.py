@@ -163,7 +163,7 @@ def packable(spec):
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
          max_period=12, vgpr_budget=120, skip_fill=1, pairs=0, align='none',
-         ring=0, waves_per_eu=0, dppadd=0, split=None, sync=1, ringpk=1, fast_store=1, prio=None, rotate=0, ntstore=0):
+         ring=0, waves_per_eu=0, dppadd=0, split=None, sync=1, ringpk=1, fast_store=1, prio=None, rotate=0, ntstore=0, ntload=0):
   """Returns (text, kernel table entry).
 
   pairs=2 (needs the ring): ONE strip of 2 x 64 x C columns per wavefront; a
@@ -323,9 +323,9 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
     for h in range(P):
       line('          __builtin_amdgcn_global_load_lds((const __attribute__(('
            'address_space(1))) void*)(g_in + row * W + %s), (__attribute__(('
-           'address_space(3))) void*)&in_ring[%d][%d][0], 16, 0, 0);'
+           'address_space(3))) void*)&in_ring[%d][%d][0], 16, 0, %d);'
            % (('x - lane * %d + %d' % (C, h * LANES * C)) if wide else
-              ('xb' if h else 'x'), slot_index, h))
+              ('xb' if h else 'x'), slot_index, h, 2 if ntload else 0))
     line('        }')
 
   def emit_body(mine, guarded):
