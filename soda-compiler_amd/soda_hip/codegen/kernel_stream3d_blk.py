@@ -172,7 +172,29 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   wavefront sums the shader cycles (s_memtime) it spends in each part of a step -
   input plane, each stage instance, the barrier - and lane 0 writes the sums there;
   scheduling fences keep the parts apart, so a stamped build is a diagnostic, not
-  the shipped kernel."""
+  the shipped kernel.
+  `nt` (bit mask): 2 = the output stores are non-temporal, 1 = the input loads, 4 = the
+  stores of launches whose box (input + output) is larger than the Infinity Cache
+  (kernel_common.NT_STREAMING_BYTES): a second instantiation of the band function,
+  chosen by the kernel's entry from the box it is given.  Stores: -6..-10 % per
+  launch beyond the cache, +5..+15 % inside it; loads: up to +35 % on the largest
+  boxes.  4 ships.
+  `mask_loads` = 1: a ragged tile fetches only the box's reach - columns right of it
+  have an out-of-range lane offset (loop-invariant), rows below it lie past the record
+  count of the plane's buffer resource (the rows ride in the scalar offset, which
+  gfx950 includes in the range check: tools/soffset_check.hip); in the ring the
+  LDS-direct loads take their buffer form (raw_ptr_buffer_load_lds).  What is not
+  fetched reads as zero and feeds only cells outside every stored cell's cone.  Ships.
+  `wide_stores` = 1: row segments are stored in whole 64-byte pieces - the cells between
+  the box and the next 64-byte boundary (outside the valid box of the level:
+  unspecified by contract, read by no later launch, stored by no other tile) get the
+  tile's values for them; 2 = only in the launches beyond the Infinity Cache (with the
+  non-temporal instantiation).  A partial piece at a box's edge costs a masked write:
+  cfg5 -2.5..-6 % under the bench protocol.  2 ships (not for packed pair-rows: heat3d
+  +3 %).
+  `skip_bands` = 1: wavefronts whose band lies outside every stored cell's cone (ragged
+  tiles at the box's y edges) end at once; the barrier counts only live wavefronts.
+  Bit-exact, no gain (those launches are bound by memory); off."""
   if spec['dim'] != 3:
     raise NotFusable('3-D programs only')
   types = specmod.tensor_c_types(spec)
