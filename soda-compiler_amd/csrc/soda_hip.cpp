@@ -718,15 +718,25 @@ int build_schedule(soda_hip_plan* plan, void* const* in, void* const* out,
       // several kernels of this depth (3-D: the wave-pipelined form with 64 x 32
       // tiles and the block form with 128 x 64 ones): the cheapest on THIS box -
       // large boxes favour the big tiles, small ones the many small ones
-      if (!empty && l.est_us > 0)
+      if (!empty && l.est_us > 0) {
+        // (tuning: SODA_HIP_PREFER=<suffix> takes the same-depth kernel whose name
+        // ends in it whatever the estimates say - tools/ compare kernel forms with it)
+        const char* prefer = tuning_env("SODA_HIP_PREFER");
+        auto preferred = [&](int k) {
+          if (!prefer) return false;
+          const size_t n = strlen(plan->kernels[k].name), m = strlen(prefer);
+          return n >= m && strcmp(plan->kernels[k].name + n - m, prefer) == 0;
+        };
         for (int k : fused) {
           if (k == seq[i] || plan->kernels[k].depth != desc.depth) continue;
           Launch other;
           bool other_empty;
           if (make_launch(plan, k, a, &other, &other_empty) == 0 && !other_empty &&
-              other.est_us > 0 && other.est_us < l.est_us)
+              other.est_us > 0 &&
+              (preferred(k) || (other.est_us < l.est_us && !preferred(l.kernel))))
             l = other;
         }
+      }
       if (!empty) list->push_back(l);
       *max_depth_used = std::max(*max_depth_used, (int)desc.depth);
       done += desc.depth;

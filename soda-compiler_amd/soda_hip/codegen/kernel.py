@@ -64,6 +64,7 @@ ALIGN_FULL_MAX_DEPTH = 2
 NT_AUTO_MAX_DEPTH_2D = 2
 # 3-D: depths beyond the single-wave form, built wave-pipelined (kernel_stream3d_wp)
 DEEP_3D_DEPTHS = (4,)
+BLOCK_3D_SHALLOW_DEPTHS = (1, 2)
 # 3-D programs light on arithmetic get TWO depth-4 kernels: the wave-pipelined one
 # (64 x 32 tiles, three workgroups per CU) and the block form (128 x 64 tiles, one
 # 8-wavefront workgroup per CU, input planes prefetched one ahead); the run-time
@@ -472,7 +473,8 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
       # rows per lane: as many as the register file allows (taller tiles waste
       # less on the y halo)
       options = {k: v for k, v in fused_options.items()
-                 if not k.startswith(('wp_', 'blk_')) and k not in ('deep3d', 'nontemporal')}
+                 if not k.startswith(('wp_', 'blk_')) and
+                 k not in ('deep3d', 'deep3d_from', 'nontemporal')}
       # (rows, columns) per lane: the tallest tile the register file allows (taller
       # tiles waste less on the y halo).  Programs with several live tensors
       # (denoise3d, lowered to g and output over the inputs f and u) fit with one
@@ -499,12 +501,21 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
       if error is not None:
         notes.append('depth %d not fused: %s' % (depth, error))
     # deeper than one wavefront's registers allow: one level per wavefront
-    deep = [d for d in (depths if depths is not None else DEEP_3D_DEPTHS)
-            if d > 2 and d <= max(1, spec['iterate'])]
+    # The block form serves the shallow depths as well (deep3d_from=3: not): next to the
+    # single-wave kernels above, which stay for arrays below its 128 x 64 tile and for
+    # programs it does not take.  jacobi3d per launch, depth 1 / 2: 512^3 470 / 395 us
+    # single-wave, 221 / 222 us block form (one read and one write of the array at 5.3
+    # TB/s: 203 us); 256^3 67 / 65 against 33 / 35; heat3d 512^3 depth 2 464 -> 231.
+    deep_from = fused_options.get('deep3d_from', 1)
+    deep = [d for d in (depths if depths is not None else
+                        BLOCK_3D_SHALLOW_DEPTHS + DEEP_3D_DEPTHS)
+            if d >= deep_from and d <= max(1, spec['iterate'])]
     if len(spec['inputs']) == len(spec['outputs']) == 1 and (
         depths is not None or arithmetic_weight(spec) <= DEEP_3D_MAX_WEIGHT):
       for depth in deep:
         form = fused_options.get('deep3d', DEEP_3D_FORM)
+        if depth < 3 and form == 'wp':      # one level per wavefront needs >= 3 levels
+          continue
         if form in ('blk', 'both'):
           # block form: all levels in every wavefront, edge rows through LDS
           # (kernel_stream3d_blk).  Named <app>_fused_k<d>b; with 'both' it ships
@@ -535,10 +546,12 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
                   raise
             parts.append(ftext)
             table.append(annotate_cost(entry, spec))
-            if form == 'blk':
+            if form == 'blk' or depth < 3:
               continue
           except kernel_stream2d.NotFusable as e:
             notes.append('depth %d not in block form: %s' % (depth, e))
+            if depth < 3:
+              continue
         options = prefixed_options(fused_options, 'wp_', kernel_stream3d_wp.emit)
         options.setdefault('groups', min(depth * len(spec['stages']), 4))
         # (no non-temporal stores here: heat3d 512^3 x20 with this form alone 2.09 ms

@@ -208,11 +208,12 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   # are unspecified by contract (include/soda_hip.h) and stored along
   assert blk[0]['wide_stores'] == 2 and 'const bool ST_WIDE = NT;' in text
   assert '* 8 > %dll' % kernel_common.NT_STREAMING_BYTES in text
-  in_registers = [k for k in kernel.generate(spec, blk_prefetch=1)[1] if k.get('stack')]
+  in_registers = [k for k in kernel.generate(spec, blk_prefetch=1)[1]
+                  if k.get('stack') and k['depth'] == 4]
   assert (in_registers[0]['prefetch'], in_registers[0]['ring']) == (1, 0)
   assert blk[0]['xcd_tiles'] == -1 and blk[0]['fill_rows'] == 8
   loose = [k for k in kernel.generate(spec, blk_align_out=2, blk_xcd_runs=0)[1]
-           if k.get('stack')]
+           if k.get('stack') and k['depth'] == 4]
   assert loose[0]['tile'][:2] == [120, 56] and loose[0]['xcd_tiles'] == 1
   assert 'edges[' in text and 'soda_lds_barrier' in text
   k4 = [k for k in table if k['kind'] == 'fused' and k['depth'] == 4 and k.get('groups')]
@@ -232,9 +233,19 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   # heavy plain-float programs: packed pair-rows in the block form too (the ring freed
   # the registers for them); hand-ordered arithmetic when asked for / pairs refused
   assert [(k['name'], k['ring'], k['pairs'], k['asm_sched']) for k in heat
-          if k.get('stack')] == [('heat3d_fused_k4b', 2, 1, 0)]
+          if k.get('stack') and k['depth'] == 4] == [('heat3d_fused_k4b', 2, 1, 0)]
   by_hand = kernel.generate(spec_of('heat3d', iterate=8), blk_pairs=0)[1]
-  assert [(k['pairs'], k['asm_sched']) for k in by_hand if k.get('stack')] == [(0, 1)]
+  assert [(k['pairs'], k['asm_sched']) for k in by_hand
+          if k.get('stack') and k['depth'] == 4] == [(0, 1)]
+  # the block form serves depths 1 and 2 as well, next to the single-wave kernels
+  # (which stay for arrays below its 128 x 64 tile and programs it does not take)
+  assert [k['name'] for k in table if k['kind'] == 'fused' and k['depth'] <= 2] == [
+      'jacobi3d_fused_k1', 'jacobi3d_fused_k2', 'jacobi3d_fused_k1b', 'jacobi3d_fused_k2b']
+  shallow = {k['name']: k for k in table if k.get('stack') and k['depth'] <= 2}
+  assert shallow['jacobi3d_fused_k1b']['tile'][:2] == [112, 62]
+  assert shallow['jacobi3d_fused_k2b']['fill_rows'] == 4
+  only_deep = kernel.generate(spec, deep3d_from=3)[1]
+  assert [k['name'] for k in only_deep if k.get('stack')] == ['jacobi3d_fused_k4b']
   out = tmp_path / 'j3d.hsaco'
   kernel.compile_to_code_object(text, str(out))
   assert open(out, 'rb').read(4) == b'\x7fELF'
@@ -361,7 +372,8 @@ def test_unfusable_programs_fall_back_to_stage_kernels():
   # 3-D single-output programs get the plane-streaming kernels
   _, table = kernel.generate(spec_of('jacobi3d'))
   fused = [k for k in table if k['kind'] == 'fused']
-  assert [k['depth'] for k in fused] == [1, 2]
+  assert [k['depth'] for k in fused] == [1, 2, 1, 2]      # single-wave, then block form
+  assert [bool(k.get('stack')) for k in fused] == [False, False, True, True]
   assert fused[1]['tile'][1] == 12 and fused[1]['fill_rows'] == 4
   # multi-input 2-D programs fuse at depth 1 with padded window lengths
   _, table = kernel.generate(spec_of('denoise2d'))

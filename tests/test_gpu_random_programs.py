@@ -140,7 +140,7 @@ def test_random_3d_chain_program(seed):
   assert key in REFERENCE
   table = run_case(key, (70, 90, 200), rng)
   assert any(k['kind'] == 'fused' for k in table)
-  if any(k.get('stack') for k in table):
+  if any(k.get('stack') and k['depth'] == 4 for k in table):
     # the block form ALONE (the scheduler may have preferred the wave-pipelined
     # kernel above), plain and with packed pair-rows where the program allows
     table = run_case(key, (70, 90, 200), np.random.default_rng(15100 + seed),

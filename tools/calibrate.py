@@ -31,7 +31,7 @@ TRACE = re.compile(r'launch\s+\d+ (\S+)\s+([\d.]+) us \(model\s+[\d.]+\)  box (\
                    r'grid (\d+) x (\d+) x (\d+)  chunk (\d+)  fill (\d+)  resident (\d+)')
 
 
-def child(app, depth, form, n, chunk):
+def child(app, depth, form, n, chunk, name=None):
   sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd')]
   import numpy as np
   from soda_hip import frontend
@@ -45,7 +45,8 @@ def child(app, depth, form, n, chunk):
   if form:
     opts['deep3d'] = form
   text, table = kernel.generate(spec, **opts)
-  mine = [k for k in table if k['kind'] == 'fused' and k['depth'] == depth]
+  mine = [k for k in table if k['kind'] == 'fused' and k['depth'] == depth and
+          (not name or k['name'] == name)]
   if not mine:
     print('NOKERNEL')
     return
@@ -75,12 +76,15 @@ def child(app, depth, form, n, chunk):
   prog.close()
 
 
-def measure(app, depth, form, n, chunk=0):
+def measure(app, depth, form, n, chunk=0, name=None):
   env = dict(os.environ, SODA_HIP_TUNING='1', SODA_HIP_LAUNCH_TRACE='1')
   if chunk:
     env['SODA_HIP_CHUNK_ROWS'] = str(chunk)
+  if name:      # several kernels of this depth in the blob: this one, whatever its price
+    env['SODA_HIP_PREFER'] = name[name.index('_fused_'):]
   p = subprocess.run([sys.executable, __file__, '--child', app, str(depth), form or '-',
-                      str(n), str(chunk)], env=env, capture_output=True, text=True)
+                      str(n), str(chunk), name or '-'], env=env, capture_output=True,
+                     text=True)
   m = re.search(r'ENTRY (.*)', p.stdout)
   launches = TRACE.findall(p.stderr)
   if not m or not launches:
@@ -121,15 +125,15 @@ def main():
       form = None
       if dim == 3 and k['depth'] > 2:
         form = 'blk' if k.get('stack') else 'wp'
-      full = measure(app, k['depth'], form, small)
+      full = measure(app, k['depth'], form, small, name=k['name'])
       if not full or full['name'] != k['name']:
         print('%-28s not measured' % k['name'])
         continue
       # <= one workgroup per CU: chunks long enough that the grid is below 256
       inner = max(1, full['blocks'] * full['chunk'] // max(1, small))
       long_chunk = min(small, -(-small * inner // 240 // 4) * 4 + 4)
-      one = measure(app, k['depth'], form, small, chunk=max(8, long_chunk))
-      stream = measure(app, k['depth'], form, big)
+      one = measure(app, k['depth'], form, small, chunk=max(8, long_chunk), name=k['name'])
+      stream = measure(app, k['depth'], form, big, name=k['name'])
       if not one or not stream:
         print('%-28s partly measured' % k['name'])
         continue
@@ -164,6 +168,7 @@ def main():
 if __name__ == '__main__':
   if len(sys.argv) > 1 and sys.argv[1] == '--child':
     child(sys.argv[2], int(sys.argv[3]), None if sys.argv[4] == '-' else sys.argv[4],
-          int(sys.argv[5]), int(sys.argv[6]))
+          int(sys.argv[5]), int(sys.argv[6]),
+          None if len(sys.argv) < 8 or sys.argv[7] == '-' else sys.argv[7])
   else:
     main()
