@@ -297,6 +297,20 @@ def roofline_block(spec, program, schedule, updates, timing, dims, iterate,
   return block
 
 
+def parse_split(text, iterate):
+  """'41x24+1x16' (config.depth_schedule of a bench line) -> [24] * 41 + [16]."""
+  depths = []
+  for part in text.split('+'):
+    count, x, depth = part.strip().partition('x')
+    if not x or not count.isdigit() or not depth.isdigit() or int(count) < 1 or int(depth) < 1:
+      raise SystemExit('--split: %r is not <count>x<depth>[+<count>x<depth>...]' % part)
+    depths += [int(depth)] * int(count)
+  if sum(depths) != iterate:
+    raise SystemExit('--split: the depths add up to %d, --iterate is %d' % (sum(depths),
+                                                                            iterate))
+  return depths
+
+
 def schedule_text(schedule):
   """'41x24+1x16' from the launch list."""
   runs = []
@@ -329,11 +343,7 @@ def run_single(args):
   sync = torch.cuda.synchronize if torch.cuda.is_available() else \
       (lambda: host.capi.check(host.capi.lib().soda_hip_stream_synchronize(None)))
   if args.split:
-    depths = []
-    for part in args.split.split('+'):
-      count, _, depth = part.partition('x')
-      depths += [int(depth)] * int(count)
-    program.set_split(dims, args.iterate, depths)
+    program.set_split(dims, args.iterate, parse_split(args.split, args.iterate))
     args.no_tune = True
   for _ in range(args.warmup):
     program.sweep(ip, op, dims, args.iterate)

@@ -50,3 +50,15 @@ def test_headline_kernel_has_fresh_traffic_and_counters():
             list(x['dims']) == [16384, 16384] and x['iterate'] == 1000]
     assert mine, newest
     assert mine[0]['kernel_digest'] == digests['jacobi2d_fused_k24'], newest
+
+
+def test_split_argument_reads_back_a_depth_schedule():
+  """bench.py --split takes what config.depth_schedule prints (the counter passes of
+  tools/collect_on_gpu.sh repeat a plain run's schedule with it)."""
+  import pytest
+  assert bench.parse_split('41x24+1x16', 1000) == [24] * 41 + [16]
+  assert bench.parse_split('5x20', 100) == [20] * 5
+  assert bench.parse_split('1x2 + 1x1', 3) == [2, 1]
+  for bad, iterate in (('41x24', 1000), ('24', 24), ('ax4', 4), ('0x4+1x4', 4), ('1x4+', 4)):
+    with pytest.raises(SystemExit):
+      bench.parse_split(bad, iterate)
