@@ -7,7 +7,10 @@ configs[3], the configuration the metric is quoted on; it fits one MI355X).
 A "step" is one whole 1000-iteration sweep of the grid, input already resident
 in HBM.  N > 1 is launched by torch.distributed.run, one rank per GPU: the grid
 is cut into N slabs along the outer dimension (strong scaling: the grid is fixed)
-and neighbours exchange ghost rows over RCCL every `--exchange` iterations.
+and neighbours exchange ghost rows over RCCL every E iterations; E and the order of
+exchange and sweeps (serial, or overlapped on a side stream) are the fastest of a few
+candidates timed during warm-up (`config.exchange_candidates_ms`), unless `--exchange`
+/ `--overlap` give them.
 
 Prints ONE JSON line (rank 0).  `value` = valid cell-updates / wall time, valid =
 the cells the reference semantics define (the box shrinks by the stencil radius
@@ -50,15 +53,21 @@ def parse_args():
   ap.add_argument('--max-depth', type=int, default=0,
                   help='cap on fused depth (0 = deepest in the blob)')
   ap.add_argument('--exchange', type=int, default=0,
-                  help='iterations between halo exchanges (0 = auto)')
+                  help='N > 1: iterations between halo exchanges (0 = the fastest of '
+                       '1, 2, 4, 8 x the deepest fused kernel, timed during warm-up)')
   ap.add_argument('--cpu-seconds', type=float, default=12.0,
                   help='CPU baseline sample budget (0 = skip)')
   ap.add_argument('--force-dist', action='store_true',
                   help='take the torch.distributed slab path even with 1 rank')
   ap.add_argument('--overlap', action='store_true',
                   help='N > 1: exchange on a side stream beside the interior '
-                       'sweep (boundary bands first); default is exchange, then '
-                       'sweep')
+                       'sweep (boundary bands first), with the default exchange '
+                       'period unless --exchange gives one; without either flag both '
+                       'orders are timed during warm-up and the faster one runs')
+  ap.add_argument('--no-exchange-tune', action='store_true',
+                  help='N > 1: keep the default exchange period and the serial order '
+                       'instead of timing the candidate (period, order) pairs during '
+                       'warm-up')
   ap.add_argument('--no-tune', action='store_true',
                   help='split `iterate` into fused depths by the calibrated model alone '
                        'instead of timing the candidate splits on this grid during '
@@ -98,11 +107,24 @@ def make_input(spec, dims, rows=None):
   for t in spec['inputs']:
     dt = np.dtype(specmod.NUMPY_NAME[t['c_type']])
     rng = np.random.default_rng(SEED)
+    wide = dt.kind != 'f' and dt.itemsize > 4     # 64-bit draws: no cheap skip
+    if rows is not None and not wide:
+      # only this rank's rows are materialised: the generator is moved past the
+      # rows before them (PCG64 makes two 32-bit draws of every 64-bit step, for
+      # float32 and for integer ranges up to 2^32 alike; advance() also drops a
+      # buffered half) - the values equal the whole grid's rows [first, last)
+      # (tests/test_bench_input.py), without 1 GiB of host memory per rank
+      row = int(np.prod(shape[1:], dtype=np.int64))
+      skip = rows[0] * row
+      rng.bit_generator.advance(skip // 2)
+      if skip % 2:
+        rng.random(1, dtype=np.float32)
+      shape = (rows[1] - rows[0],) + shape[1:]
     if dt.kind == 'f':
       a = rng.random(shape, dtype=np.float32).astype(dt, copy=False)
     else:
       a = rng.integers(0, np.iinfo(dt).max + 1, size=shape).astype(dt)
-    if rows is not None:
+    if rows is not None and wide:
       a = np.ascontiguousarray(a[rows[0]:rows[1]])
     out.append(a)
   return out

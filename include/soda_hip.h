@@ -322,8 +322,10 @@ int soda_hip_plan_set_out_final_only(soda_hip_plan* plan, int on);
  * done so far.  Same logic as soda_hip/runtime/dist.py (the torch.distributed
  * driver, covered by world-size 2 and 3 tests); this entry exists so that a C or
  * C++ caller - the generated `<app>()` - can shard without Python.  librccl.so is
- * loaded on first use.  NOTE: with world > 1 this path has not run on hardware
- * yet (no multi-GPU box was available); world == 1 is tested. */
+ * loaded on first use.  Tested with world == 1 on the real library and with world
+ * 2 and 3 over a test-only stand-in for librccl.so (ranks = host threads sharing one
+ * GPU, tests/rccl_standin): every line below the ABI runs; what has NOT run yet is
+ * real RCCL with more than one rank (no multi-GPU box was available). */
 typedef struct soda_hip_slab {
   int32_t rank, world;
   int32_t reach_lo, reach_hi; /* per-iteration stencil reach along the outermost

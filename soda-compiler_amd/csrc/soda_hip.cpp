@@ -85,6 +85,7 @@ struct soda_hip_plan {
   // reach every CU (jacobi3d 128^3, depth 4: 67 us per launch with 32-plane
   // chunks)
   int chunk_rows_min = 8;
+  int wgs_per_cu_cap = 0;            // SODA_HIP_WGS_PER_CU, for tuning (see make_launch)
   bool chunk_tie_short = false;      // SODA_HIP_CHUNK_TIE_SHORT, for tuning
   bool chunk_by_time = false;        // SODA_HIP_CHUNK_BY_TIME, for tuning
   // soda_hip_plan_set_out_final_only: `out` is written by the LAST launch of a sweep
@@ -244,6 +245,7 @@ struct Launch {
   soda_hip_args args;
   unsigned grid[3];
   double est_us;   // modelled duration (0 = the kernel carries no cost figures)
+  unsigned lds_bytes = 0;   // dynamic LDS asked for only to cap the workgroups per CU
 };
 
 // Cost model of a streaming launch (what the scheduler compares depths with; it
@@ -296,6 +298,23 @@ double step_seconds(const soda_hip_plan* plan, int k, double blocks, double foot
   return std::max(valu, hbm);
 }
 
+// bytes a launch streams: its box, every input and output
+double footprint_of(const soda_hip_plan* plan, const soda_hip_args& args) {
+  const soda_hip_program& p = plan->prog;
+  double cells = 1;
+  for (int e = 0; e < p.dim; ++e) cells *= (double)(args.box_hi[e] - args.box_lo[e]);
+  double footprint = 0;
+  for (int j = 0; j < p.n_inputs; ++j) footprint += cells * p.elem_size[j];
+  for (int j = 0; j < p.n_outputs; ++j) footprint += cells * p.elem_size[p.output_tensor[j]];
+  return footprint;
+}
+
+int streaming_cap(const soda_hip_plan* plan, int k, double footprint) {
+  (void)k;
+  (void)footprint;
+  return plan->wgs_per_cu_cap;
+}
+
 int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
                 Launch* out, bool* empty) {
   const soda_hip_kernel& desc = plan->kernels[k];
@@ -303,6 +322,7 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
   out->kernel = k;
   out->args = args;
   out->est_us = 0;
+  out->lds_bytes = 0;
   *empty = false;
   // never launch a box that sticks out of the array
   for (int d = 0; d < dim; ++d)
@@ -334,18 +354,19 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
       // that is 2.4 chip-fulls costs 3, so aim for whole rounds.
       int64_t inner = 1;
       for (int e = 0; e < dim - 1; ++e) inner *= out->grid[e];
-      const int64_t resident = std::max(1, plan->resident_blocks[k]);
+      int64_t resident = std::max(1, plan->resident_blocks[k]);
+      // A cap on the workgroups a CU holds at once (streaming launches of the
+      // memory-bound kernels: fewer wavefronts walking longer chunks keep the set of
+      // DRAM pages the chip touches at a time small - tools/copyceil.hip): enforced
+      // with dynamic LDS the kernel never uses, 160 KiB / (cap + 1) + 1 KiB each
+      const int cap = streaming_cap(plan, k, footprint_of(plan, args));
+      if (cap > 0 && resident > (int64_t)cap * plan->cus) {
+        resident = (int64_t)cap * plan->cus;
+        out->lds_bytes = 160u * 1024u / (unsigned)(cap + 1) + 1024u;
+      }
       int64_t best = tile, best_cost = -1;
       double best_time = -1;
-      double footprint = 0;      // bytes the launch streams: its box, in and out
-      {
-        double cells = 1;
-        for (int e = 0; e < dim; ++e) cells *= (double)(args.box_hi[e] - args.box_lo[e]);
-        const soda_hip_program& p = plan->prog;
-        for (int j = 0; j < p.n_inputs; ++j) footprint += cells * p.elem_size[j];
-        for (int j = 0; j < p.n_outputs; ++j)
-          footprint += cells * p.elem_size[p.output_tensor[j]];
-      }
+      const double footprint = footprint_of(plan, args);
       const int64_t shortest = plan->chunk_rows_min;   // 8; SODA_HIP_CHUNK_MIN
       for (int64_t chunk = shortest;
            chunk <= std::max<int64_t>(shortest, std::min<int64_t>(extent, 4096));
@@ -809,7 +830,7 @@ int launch_one(const soda_hip_plan* plan, const Launch& l, hipStream_t stream) {
   HIP_TRY(SODA_HIP_ERR_DEVICE_RUN,
           hipModuleLaunchKernel(plan->funcs[l.kernel], l.grid[0], l.grid[1],
                                 l.grid[2], desc.block[0], desc.block[1],
-                                desc.block[2], 0, stream, nullptr, config));
+                                desc.block[2], l.lds_bytes, stream, nullptr, config));
   return 0;
 }
 
@@ -1091,6 +1112,7 @@ int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* progra
     }
   }
   if (const char* env = tuning_env("SODA_HIP_CHUNK_ROWS")) pl->chunk_rows_override = atoi(env);
+  if (const char* env = tuning_env("SODA_HIP_WGS_PER_CU")) pl->wgs_per_cu_cap = atoi(env);
   if (tuning_env("SODA_HIP_CHUNK_TIE_SHORT")) pl->chunk_tie_short = true;
   if (tuning_env("SODA_HIP_CHUNK_BY_TIME")) pl->chunk_by_time = true;
   if (const char* env = tuning_env("SODA_HIP_CHUNK_MIN"))

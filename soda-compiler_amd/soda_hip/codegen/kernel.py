@@ -387,17 +387,25 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
       if piped is not None:
         pass
       elif groups <= 1 or depth < WAVE_PIPELINE_MIN_DEPTH or groups == -1:
-        try:
-          # the memory-bound depths store around the caches when a launch's box
-          # does not fit the Infinity Cache (kernel_stream2d.emit: nontemporal)
-          single = kernel_stream2d.emit(
-              spec, depth, **common,
-              **dict({'nontemporal': 4} if depth <= NT_AUTO_MAX_DEPTH_2D else {},
-                     **{k: v for k, v in fused_options.items()
-                        if k not in WP_ONLY_OPTIONS and not k.startswith('k1_') and
-                        k != 'nt'}))
-        except kernel_stream2d.NotFusable as e:
-          notes.append('depth %d not fused: %s' % (depth, e))
+        # the memory-bound depths store around the caches when a launch's box
+        # does not fit the Infinity Cache (kernel_stream2d.emit: nontemporal)
+        options = dict({'nontemporal': 4} if depth <= NT_AUTO_MAX_DEPTH_2D else {},
+                       **{k: v for k, v in fused_options.items()
+                          if k not in WP_ONLY_OPTIONS and not k.startswith('k1_') and
+                          k != 'nt'})
+        # ... and where no STAGE is read across lanes (depth 1 of the samples) their
+        # strips do not overlap at all (align='exact': whole 128-byte lines in and
+        # out, the seam columns from one extra vector load per row and side)
+        aligns = ['exact', 'full'] if common.get('align') == 'full' else \
+            [options.pop('align', None) or common['align']]
+        for k, how in enumerate(aligns):
+          try:
+            single = kernel_stream2d.emit(spec, depth, **dict(common, align=how),
+                                          **options)
+            break
+          except kernel_stream2d.NotFusable as e:
+            if k == len(aligns) - 1:
+              notes.append('depth %d not fused: %s' % (depth, e))
       want_piped = piped is None and depth >= WAVE_PIPELINE_MIN_DEPTH and (
           groups > 1 or (groups == -1 and (
               single is None or single[1]['est_vgprs'] > AUTO_WP_VGPRS or

@@ -250,6 +250,40 @@ template <typename T> DEV void rows_across_halves(T first, T last, T& above, T& 
   above = __builtin_bit_cast(T, (unsigned)r[0]);
   below = __builtin_bit_cast(T, (unsigned)r[1]);
 }
+// ... where the lane without such a neighbour keeps `edge` instead of receiving 0 (DPP
+// without bound_ctrl leaves `old` in lanes that have no source lane): the first / last
+// lane of a seam-free strip (kernel_stream2d, align='exact') hold there what the strip's
+// edge loads fetched
+template <typename T, bool BELOW> DEV T lane_neighbour_or(T v, T edge) {
+  if constexpr (sizeof(T) == 8) {
+    struct halves { int lo, hi; };
+    halves h = __builtin_bit_cast(halves, v), e = __builtin_bit_cast(halves, edge);
+    h.lo = BELOW ? __builtin_amdgcn_update_dpp(e.lo, h.lo, 0x138, 0xf, 0xf, false)
+                 : __builtin_amdgcn_update_dpp(e.lo, h.lo, 0x130, 0xf, 0xf, false);
+    h.hi = BELOW ? __builtin_amdgcn_update_dpp(e.hi, h.hi, 0x138, 0xf, 0xf, false)
+                 : __builtin_amdgcn_update_dpp(e.hi, h.hi, 0x130, 0xf, 0xf, false);
+    return __builtin_bit_cast(T, h);
+  } else {
+    int w, o;
+    if constexpr (sizeof(T) == 4) {
+      w = __builtin_bit_cast(int, v);
+      o = __builtin_bit_cast(int, edge);
+    } else if constexpr (sizeof(T) == 2) {
+      w = __builtin_bit_cast(unsigned short, v);
+      o = __builtin_bit_cast(unsigned short, edge);
+    } else {
+      w = __builtin_bit_cast(unsigned char, v);
+      o = __builtin_bit_cast(unsigned char, edge);
+    }
+    const int r = BELOW ? __builtin_amdgcn_update_dpp(o, w, 0x138, 0xf, 0xf, false)
+                        : __builtin_amdgcn_update_dpp(o, w, 0x130, 0xf, 0xf, false);
+    if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, r);
+    else if constexpr (sizeof(T) == 2) return __builtin_bit_cast(T, (unsigned short)r);
+    else return __builtin_bit_cast(T, (unsigned char)r);
+  }
+}
+template <typename T> DEV T from_lane_below_or(T v, T edge) { return lane_neighbour_or<T, true>(v, edge); }
+template <typename T> DEV T from_lane_above_or(T v, T edge) { return lane_neighbour_or<T, false>(v, edge); }
 template <typename T> DEV T from_lane_below_bp(T v) { return lane_neighbour_bp<T, true>(v); }
 template <typename T> DEV T from_lane_above_bp(T v) { return lane_neighbour_bp<T, false>(v); }
 template <typename T> DEV T from_lane_below(T v) { return lane_neighbour<T, true>(v); }

@@ -109,7 +109,14 @@ def geometry(spec, depth, cols, chunk_rows, align='none'):
   align: 'none'  - strips as wide as the halo allows;
          'store' - every strip's OUTPUT columns start and end on a 128-byte line
                    (no line is written by two wavefronts);
-         'full'  - the loaded columns start on a line as well.
+         'full'  - the loaded columns start on a line as well;
+         'exact' - strips do not overlap at all: a wavefront loads and stores exactly
+                   its own 64 * cols columns, whole 128-byte lines on both sides, and
+                   the columns its first and last lane need from beyond the strip come
+                   from one extra vector load each per input row (`emit`, edge loads).
+                   Only for kernels whose lane-crossing reads are all on loaded inputs
+                   (depth 1 of the samples): a stage read across lanes would have to be
+                   computed beyond the strip, which is what the overlap is for.
   Measured with the kernels' access pattern on a 16384x16384 float array
   (tools/copybench.hip, strips of 256 loaded columns): 248 out / halo 4 508 us,
   232/12 520 us, 224/16 487 us, 224/0 (both aligned) 445 us, 192/32 431 us,
@@ -130,13 +137,17 @@ def geometry(spec, depth, cols, chunk_rows, align='none'):
     line -= line % cols
   if align in ('full', 'full64'):
     halo_lo = -(-lo[0] // line) * line
+  if align == 'exact':
+    halo_lo = halo_hi = 0
   w_out = LANES * cols - halo_lo - halo_hi
   origin_align = cols
-  if align in ('store', 'store64', 'full', 'full64') and w_out >= line:
+  if align == 'exact':
+    origin_align = line
+  elif align in ('store', 'store64', 'full', 'full64') and w_out >= line:
     w_out -= w_out % line
     halo_hi = LANES * cols - halo_lo - w_out
     origin_align = line
-  elif align not in ('none', 'store', 'store64', 'full', 'full64'):
+  elif align not in ('none', 'store', 'store64', 'full', 'full64', 'exact'):
     raise ValueError('align: %r' % (align,))
   if w_out < cols:
     raise NotFusable('depth %d leaves no output columns in a strip' % depth)
@@ -181,6 +192,24 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
       if abs(rel[0]) > cols:
         raise NotFusable('x offset %d exceeds the %d columns a lane holds'
                          % (rel[0], cols))
+  exact = align == 'exact'
+  for inst in insts:
+    inst.edges = 0      # columns beyond the strip, per side, that readers ask for
+  if exact:
+    # which instances are needed beyond the strip (C columns on either side, held by the
+    # first and the last lane): those read across lanes - and what THEY are computed
+    # from, which must then be read at x offset 0 only (blur: blur_y reads blur_x across
+    # lanes, blur_x reads the input straight up: both get edge vectors, the input's
+    # loaded, blur_x's computed from them)
+    for inst in reversed(insts):
+      for src, rel, _ in inst.reads:
+        src.edges = max(src.edges, abs(rel[0]))
+      if inst.edges and inst.stage is not None:
+        for src, rel, _ in inst.reads:
+          if rel[0]:
+            raise NotFusable('seam-free strips: stage %s is read across lanes and reads '
+                             '%s across lanes itself' % (inst.tensor, src.tensor))
+          src.edges = max(src.edges, inst.edges)
   # Rotation period: the row loop is unrolled `period` times so that every
   # window's "shift" is a renaming; each keep must divide it.  Keeping MORE rows
   # than needed is always legal, so keeps are rounded up to divisors of the
@@ -205,8 +234,9 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
     inst.keep = keep
   # register budget: every retained row costs C VGPRs per lane (2C for 8-byte
   # types); past ~224 the kernel drops below two waves per SIMD and then spills
-  est_vgprs = sum(inst.keep * cols * max(1, specmod.ELEM_SIZE[inst.c_type] // 4)
-                  for inst in insts) + 4 * cols + 16
+  est_vgprs = sum(inst.keep * (cols + 2 * inst.edges) *
+                  max(1, specmod.ELEM_SIZE[inst.c_type] // 4) for inst in insts) + \
+      4 * cols + 16
   if est_vgprs > vgpr_budget:
     raise NotFusable('depth %d would need about %d VGPRs (budget %d)'
                      % (depth, est_vgprs, vgpr_budget))
@@ -249,6 +279,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
             % (T_in, vec_in, C, elem))
   emit_line('typedef %s %s __attribute__((ext_vector_type(%d), aligned(%d)));'
             % (T_out, vec_out, C, elem))
+  emit_line('typedef unsigned soda_u2 __attribute__((ext_vector_type(2)));')
+  emit_line('typedef unsigned soda_u4 __attribute__((ext_vector_type(4)));')
   # nontemporal: 1 = loads, 2 = stores, 4 = the stores of launches whose box does not
   # fit the Infinity Cache (kernel_common.NT_STREAMING_BYTES), as an instantiation of
   # the steady interior path chosen per launch.  Per launch at 16384^2, stores always /
@@ -272,14 +304,37 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
   if steady:
     emit_line('  const bool st_full = x >= st_lo && x + %d <= st_hi;' % C)
   for inst in insts:
-    if inst.keep:
+    # seam-free strips: a loaded row stays the VECTOR it arrived as until its cells are
+    # used (sub-dword elements are unpacked there; unpacked at the load - behind the
+    # scheduling fence of its step - every row would be waited for as soon as issued)
+    inst.packed = exact and inst.stage is None and inst.c_type == in_type
+    if inst.keep and inst.packed:
+      emit_line('  %s %s[%d];' % (vec_in, inst.ident, inst.keep))
+    elif inst.keep:
       emit_line('  %s %s[%d][%d];' % (builtin_type(inst.c_type), inst.ident,
                                      inst.keep, C))
+    if inst.edges:
+      # seam-free strips: column k left of the strip (edge_lo: column xs - 1 - k) and
+      # right of it (edge_hi: xs + 64 C + k) of every live row - what a lane below the
+      # first / above the last one would hold - in every lane (lanes 0 and 63 use them).
+      # Two registers rather than one shared by the halves of the wavefront: a register
+      # read by two DPP moves is copied first, and the scheduler hoists that copy to the
+      # top of the row loop, where it waits for the load issued last
+      for side in ('lo', 'hi'):
+        emit_line('  %s edge_%s_%s[%d][%d];' % (builtin_type(inst.c_type), side, inst.ident,
+                                               inst.keep, inst.edges))
   # windows start as zeros so that the prologue computes on defined values
   for inst in insts:
     for r in range(inst.keep):
       emit_line('  ' + ' '.join('%s[%d][%d] = 0;' % (inst.ident, r, c)
                                 for c in range(C)))
+      for side in ('lo', 'hi') if inst.edges else ():
+        emit_line('  ' + ' '.join('edge_%s_%s[%d][%d] = 0;' % (side, inst.ident, r, c)
+                                  for c in range(inst.edges)))
+  # (seam-free strips: EVERY lane loads the edge columns, one element per column and side
+  # at a wave-uniform address: no branch in the row loop - under a branch the compiler
+  # waits for all loads in flight at the join.  Clamped into the row where the array has
+  # no such column: those values feed only cells outside every valid box.)
   emit_line('  // load head: first input row the chunk depends on')
   emit_line('  i64 head = y0 - %d;' % geo['y_lo'])
   emit_line('  const i64 steps = (y1 - y0) + %d;' % (L + geo['y_lo']))
@@ -300,6 +355,13 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
     if 0 <= j < C:
       return '%s[%d]' % (row, j)
     suffix = '_bp' if bpermute else ''
+    if exact:       # the first / last lane take the column from the strip's edge loads
+      assert src.edges
+      if j < 0:
+        return 'from_lane_below_or(%s[%d], edge_lo_%s[%d][%d])' % (
+            row, C + j, src.ident, slot(src, u, back), -j - 1)
+      return 'from_lane_above_or(%s[%d], edge_hi_%s[%d][%d])' % (
+          row, j - C, src.ident, slot(src, u, back), j - C)
     if j < 0:
       return 'from_lane_below%s(%s[%d])' % (suffix, row, C + j)
     return 'from_lane_above%s(%s[%d])' % (suffix, row, j - C)
@@ -323,7 +385,9 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
                       % (vec_in, vec_in))
           else:
             emit_line('          const %s v = *(const %s*)p;' % (vec_in, vec_in))
-          for c in range(C):
+          if inst.packed:
+            emit_line('          %s[%d] = v;' % (inst.ident, s))
+          for c in range(0 if inst.packed else C):
             emit_line('          %s[%d][%d] = v[%d];' % (inst.ident, s, c, c))
           emit_line('        } else {')
           for c in range(C):
@@ -331,6 +395,15 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
                       '(%s)0;' % (inst.ident, s, c, c, c, c,
                                   builtin_type(inst.c_type)))
           emit_line('        }')
+          for k in range(inst.edges):
+            for side, ex in (('lo', 'xs - %d' % (k + 1)), ('hi', 'xs + %d' % (LANES * C + k))):
+              emit_line('        { i64 ex = %s;' % ex)
+              emit_line('          if (INTERIOR) { if (ex < 0) ex = 0; if (ex > W - 1) ex = W - 1; '
+                        'edge_%s_%s[%d][%d] = g_%s[row * W + ex]; }' % (
+                            side, inst.ident, s, k, inst.tensor))
+              emit_line('          else edge_%s_%s[%d][%d] = (ex >= 0 && ex < W) ? '
+                        'g_%s[row * W + ex] : (%s)0; }' % (side, inst.ident, s, k, inst.tensor,
+                                                           builtin_type(inst.c_type)))
           emit_line('      }')
           continue
         stage = inst.stage
@@ -349,19 +422,41 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
           target = ('out_row[%d]' % c) if inst.final else \
               '%s[%d][%d]' % (inst.ident, slot(inst, u, 0), c)
           cell_assignment(stage, target, load, emit_line, '      ')
+        for side in ('lo', 'hi') if inst.edges else ():
+          # the same row beyond the strip, from the sources' edge columns
+          for c in range(inst.edges):
+            def load_edge(tensor, rel, u=u, c=c, inst=inst, by_name=by_name, side=side):
+              src = by_name[(tensor, tuple(rel))]
+              back = inst.lag - src.lag - rel[1]
+              return 'edge_%s_%s[%d][%d]' % (side, src.ident, slot(src, u, back), c)
+            cell_assignment(stage, 'edge_%s_%s[%d][%d]' % (side, inst.ident,
+                                                           slot(inst, u, 0), c),
+                            load_edge, emit_line, '      ')
         if inst.final:
           emit_line('      {  // store row head+%d-%d' % (u, L))
           emit_line('        const i64 y = head + %d;' % (u - L))
           emit_line('        %s{' % ('' if calm else 'if (y >= y0 && y < y1) '))
           emit_line('          %s* q = g_out + y * W + x;' % T_out)
-          if calm:
+          if calm and exact:      # !RAGGED: every lane of the strip stores all its columns
+            emit_line('          if (!RAGGED || (x >= st_lo && x + %d <= st_hi)) {' % C)
+          elif calm:
             emit_line('          if (RAGGED ? (x >= st_lo && x + %d <= st_hi) : st_full) {' % C)
           else:
             emit_line('          if (x >= st_lo && x + %d <= st_hi) {' % C)
           emit_line('            %s v;' % vec_out)
           for c in range(C):
             emit_line('            v[%d] = out_row[%d];' % (c, c))
-          if nt_auto:
+          if nt_auto and exact and vec_bytes in (4, 8, 16):
+            # (as a raw buffer store on the row: behind __builtin_nontemporal_store the
+            # compiler waits for EVERY access in flight once per trip of the row loop -
+            # s_waitcnt vmcnt(0) where the plain store has vmcnt(4) - which empties the
+            # pipeline of loads this loop exists for)
+            bits = {4: ('b32', 'unsigned'), 8: ('b64', 'soda_u2'), 16: ('b128', 'soda_u4')}[vec_bytes]
+            emit_line('            if (NT) __builtin_amdgcn_raw_buffer_store_%s(__builtin_bit_cast('
+                      '%s, v), __builtin_amdgcn_make_buffer_rsrc((void*)(g_out + y * W), 0, '
+                      '(int)(W * %d), 0x27000), (unsigned)(x * %d), 0, 2); else *(%s*)q = v;' % (
+                          bits[0], bits[1], elem, elem, vec_out))
+          elif nt_auto:
             emit_line('            if (NT) __builtin_nontemporal_store(v, (%s*)q); '
                       'else *(%s*)q = v;' % (vec_out, vec_out))
           elif nontemporal & 2:
@@ -378,6 +473,12 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
         if skip:
           emit_line('      }')
       emit_line('    }')
+      if calm and exact:
+        # a scheduling fence per row: nothing that uses a row moves up across the loads
+        # issued after it (a use hoisted to the top of the loop waits for the load
+        # issued LAST - vmcnt(0) once per trip - and the pipeline of rows in flight
+        # drains there)
+        emit_line('    __builtin_amdgcn_sched_barrier(0);')
 
   if prologue_steps:
     emit_line('  // pipeline fill: instances start as their windows become useful')
@@ -449,8 +550,11 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
     emit_line('  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];')
     emit_line('  const i64 st_hi = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];'
               % (geo['w_out'], geo['w_out']))
-    emit_line('  const bool partial = !(x >= st_lo && x + %d <= st_hi) && (%s);' % (
-        C, ' || '.join('(x + %d >= st_lo && x + %d < st_hi)' % (c, c) for c in range(C))))
+    if exact:      # seam-free strips: no halo lanes - `ragged` = not every lane stores
+      emit_line('  const bool partial = !(x >= st_lo && x + %d <= st_hi);' % C)
+    else:
+      emit_line('  const bool partial = !(x >= st_lo && x + %d <= st_hi) && (%s);' % (
+          C, ' || '.join('(x + %d >= st_lo && x + %d < st_hi)' % (c, c) for c in range(C))))
     emit_line('  const bool ragged = __builtin_amdgcn_ballot_w64(partial) != 0;')
     emit_line('  if (!interior) %s_strip<false, true>(a, xs, x, y0, y1);' % name)
     emit_line('  else if (ragged) %s_strip<true, true>(a, xs, x, y0, y1);' % name)
@@ -474,6 +578,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
                cols=C, prefetch=prefetch, period=period, est_vgprs=est_vgprs,
                halo=[geo['halo_lo'], geo['halo_hi']], w_out=geo['w_out'],
                steady=int(steady))
+  if exact:
+    entry['exact'] = 1
   if nontemporal:
     entry['nontemporal'] = int(nontemporal)
   return '\n'.join(o) + '\n', entry

@@ -119,12 +119,17 @@ class SerialSchedule:
   """How run_slab orders the exchange against the sweeps: here, not at all (the
   CPU engines of the gloo tests, and the reference point on GPUs)."""
   overlapped = False
+  # True: the exchanges are left out (stale ghost rows; results are garbage, launch
+  # times are not - they do not depend on the data): what the compute of a rank's
+  # slab costs by itself (bench_main: compute_only_ms_per_step)
+  skip_exchange = False
 
   def before_super_step(self):
     pass
 
   def exchange(self, fn):
-    fn()
+    if not self.skip_exchange:
+      fn()
 
   def after_bands(self):
     pass
@@ -232,6 +237,36 @@ def auto_exchange(own_rows, reach, deepest, iterate):
   return max(1, min(e, iterate))
 
 
+def exchange_candidates(smallest_own, reach, deepest, iterate):
+  """Exchange periods worth timing: 1, 2, 4 and 8 times the deepest fused kernel,
+  none with ghost regions deeper than the thinnest slab (SlabPlan's clamp) and none
+  beyond the iteration count; duplicates dropped, ascending."""
+  cap = max(1, min(iterate, smallest_own // max(1, reach)))
+  out = []
+  for multiple in (1, 2, 4, 8):
+    e = max(1, min(deepest * multiple, cap))
+    if e not in out:
+      out.append(e)
+  return out
+
+
+def choose_exchange(candidates, time_step, reduce_max):
+  """Times one step of every (exchange period, overlapped) pair and returns
+  (table, chosen): table = [dict(exchange=E, overlapped=bool, ms=slowest rank's time)],
+  chosen = its fastest row (the first of equals).
+
+  `time_step(E, overlapped)` -> seconds on THIS rank; `reduce_max(list of seconds)` ->
+  the element-wise maximum over all ranks.  Every rank sees the same table and therefore
+  takes the same pair - a rank that chose another exchange period would wait for
+  messages nobody sends."""
+  local = [time_step(e, overlapped) for e, overlapped in candidates]
+  slowest = reduce_max(local)
+  table = [dict(exchange=e, overlapped=bool(o), ms=float(t) * 1e3)
+           for (e, o), t in zip(candidates, slowest)]
+  chosen = min(table, key=lambda row: row['ms'])
+  return table, chosen
+
+
 # ---------------------------------------------------------------------------
 # the HIP engine + bench driver (GPU only)
 # ---------------------------------------------------------------------------
@@ -289,6 +324,8 @@ class StreamSchedule:
     self.side.wait_event(self.bands_done)
 
   def exchange(self, fn):
+    if self.skip_exchange:
+      return
     main = self.torch.cuda.current_stream()
     # the rows to be sent were produced on the main stream (the input, the band
     # sweeps, or - small slabs - a whole-slab sweep): the side stream follows
@@ -326,6 +363,8 @@ class TimedSerialSchedule(SerialSchedule):
     self.spans = []
 
   def exchange(self, fn):
+    if self.skip_exchange:
+      return
     t0 = self.torch.cuda.Event(enable_timing=True)
     t1 = self.torch.cuda.Event(enable_timing=True)
     t0.record()
@@ -370,23 +409,34 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
     r_lo, r_hi = spec['radius']['lo'][-1], spec['radius']['hi'][-1]
     deepest = max([k['depth'] for k in program.kernels if k['kind'] == 'fused'
                    and (args.max_depth <= 0 or k['depth'] <= args.max_depth)] or [1])
-    own_guess = dims[-1] // world
-    exchange = args.exchange or auto_exchange(own_guess, max(r_lo, r_hi, 1),
-                                              deepest, args.iterate)
-    plan = SlabPlan(dims, rank, world, r_lo, r_hi, exchange)
+    bounds = slab_bounds(dims[-1], world)
+    start, stop = bounds[rank]
+    smallest = min(b1 - b0 for b0, b1 in bounds)
+    reach = max(r_lo, r_hi, 1)
     dt = program.in_dtypes[0]
     tdt = {'float32': torch.float32, 'float64': torch.float64,
            'uint16': torch.uint16, 'int16': torch.int16, 'uint8': torch.uint8,
            'int32': torch.int32}[dt.name]
-    shape = tuple(reversed(plan.local_dims))
-    # the rank's slab of the global seeded input, plus room for ghosts
-    own = make_input(spec, dims, rows=(plan.start, plan.stop))[0]
     dev = torch.device('cuda', local_rank)
-    a = torch.zeros(shape, dtype=tdt, device=dev)
-    a[plan.ghost_lo:plan.ghost_lo + plan.own].copy_(torch.from_numpy(own))
-    b = torch.zeros_like(a)
-    c = torch.zeros_like(a)
-    del own
+    given = bool(args.exchange) or bool(getattr(args, 'overlap', False)) or \
+        bool(getattr(args, 'no_exchange_tune', False)) or world == 1
+    # Which (exchange period, order) pairs to time: unless given on the command line,
+    # E = 1, 2, 4, 8 x the deepest fused kernel, each serial and overlapped - the two
+    # knobs that decide an N > 1 run and that one GPU cannot measure
+    if given:
+      pairs = [(args.exchange or auto_exchange(dims[-1] // world, reach, deepest,
+                                               args.iterate),
+                bool(getattr(args, 'overlap', False)) and world > 1)]
+    else:
+      pairs = [(e, o) for e in exchange_candidates(smallest, reach, deepest, args.iterate)
+               for o in (False, True)]
+    # this rank's rows of the global seeded input stay on the device; every candidate
+    # builds its slab (own rows + ITS ghost rows) as a view of three arrays sized for
+    # the deepest ghost regions
+    own_rows = torch.from_numpy(make_input(spec, dims, rows=(start, stop))[0]).to(dev)
+    deepest_plan = SlabPlan(dims, rank, world, r_lo, r_hi, max(e for e, _ in pairs))
+    full_shape = tuple(reversed(deepest_plan.local_dims))
+    storage = [torch.zeros(full_shape, dtype=tdt, device=dev) for _ in range(3)]
     engine = HipEngine(program, torch)
     margin_table = specmod.iteration_margins(spec, args.iterate)
 
@@ -395,47 +445,90 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
         return (0,) * spec['dim'], (0,) * spec['dim']
       return margin_table[k - 1]
 
-    overlap = bool(getattr(args, 'overlap', False)) and world > 1
-    order = (StreamSchedule if overlap else TimedSerialSchedule)(
-        torch, host_sync=backend != 'nccl')
+    def setup(exchange, overlapped):
+      """(plan, [a, b, c], order, step) of one candidate: a holds the own rows at
+      level 0, ghost rows anything - every step exchanges them first."""
+      plan = SlabPlan(dims, rank, world, r_lo, r_hi, exchange)
+      a, b, c = (t[:plan.local_extent] for t in storage)
+      a[plan.ghost_lo:plan.ghost_lo + plan.own].copy_(own_rows)
+      order = (StreamSchedule if overlapped else TimedSerialSchedule)(
+          torch, host_sync=backend != 'nccl')
 
-    # Every exchange is inside the timed region, the level-0 one included: a step
-    # starts from own rows only, as a fresh input would arrive.
-    def step():
-      return run_slab(engine, plan, [a, b, c], args.iterate, margins_of, dist,
-                      schedule=order)
+      # Every exchange is inside the timed region, the level-0 one included: a step
+      # starts from own rows only, as a fresh input would arrive.
+      def step():
+        return run_slab(engine, plan, [a, b, c], args.iterate, margins_of, dist,
+                        schedule=order)
+      return plan, (a, b, c), order, step
+
+    def tune_split(plan, arrays):
+      # untimed: the candidate splits of a super-step on this rank's slab
+      # (soda_hip_plan_tune; no communication inside)
+      if not getattr(args, 'no_tune', False) and args.iterate > 1:
+        torch.cuda.synchronize()
+        program.tune([arrays[0].data_ptr()], [arrays[1].data_ptr()], plan.local_dims,
+                     min(plan.exchange, args.iterate),
+                     stream=torch.cuda.current_stream().cuda_stream)
+
+    def reduce_max(seconds):
+      t = torch.tensor(list(seconds), dtype=torch.float64,
+                       device=dev if backend == 'nccl' else 'cpu')
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      return [float(v) for v in t.tolist()]
+
+    def fenced(fn, repeats):
+      """Seconds `repeats` calls of fn take on this rank, between two barriers."""
+      torch.cuda.synchronize()
+      dist.barrier()
+      torch.cuda.synchronize()
+      t0, out = time.perf_counter(), None
+      for _ in range(repeats):
+        out = fn()
+      torch.cuda.synchronize()
+      dist.barrier()
+      torch.cuda.synchronize()
+      return time.perf_counter() - t0, out
 
     # a true collective first: batched point-to-point calls may involve a subset of
     # the ranks only AFTER the group's first collective (torch.distributed docs)
     dist.barrier()
     # one untimed exchange in any case: RCCL builds its point-to-point channels
     # on first use (seconds), which must not land in a run started with --warmup 0
-    exchange_ghosts(a, plan, dist)
+    plan, arrays, order, step = setup(*pairs[0])
+    exchange_ghosts(arrays[0], plan, dist)
+    table = None
+    if len(pairs) > 1:
+      tuned = set()
+
+      def time_step(exchange, overlapped):
+        plan, arrays, order, step = setup(exchange, overlapped)
+        if exchange not in tuned:
+          tune_split(plan, arrays)
+          tuned.add(exchange)
+        step()                                   # untimed: clocks, channels, scratch
+        return fenced(step, 1)[0]
+      table, chosen = choose_exchange(pairs, time_step, reduce_max)
+      plan, arrays, order, step = setup(chosen['exchange'], chosen['overlapped'])
+    overlap = order.overlapped
+    a, b, c = arrays
     for _ in range(args.warmup):
       step()
-    if not getattr(args, 'no_tune', False) and args.iterate > 1:
-      # untimed: the candidate splits of a super-step on this rank's slab
-      # (soda_hip_plan_tune; no communication inside)
-      torch.cuda.synchronize()
-      program.tune([a.data_ptr()], [b.data_ptr()], plan.local_dims,
-                   min(plan.exchange, args.iterate),
-                   stream=torch.cuda.current_stream().cuda_stream)
+    if table is None:
+      tune_split(plan, arrays)
       step()
     torch.cuda.synchronize()
     order.exchange_ms()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-      _, exchanges = step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
-                           device=dev if backend == 'nccl' else 'cpu')
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    wall = float(elapsed.item())
+    seconds, (_, exchanges) = fenced(step, args.steps)
+    wall = reduce_max([seconds])[0]
     exchange_ms = order.exchange_ms() / max(1, args.steps)
+    # the same steps with the exchanges left out (stale ghost rows: launch times do not
+    # depend on the data): separates what the slabs' redundant rows and pipeline fill
+    # cost from what the exchange over xGMI costs
+    order.skip_exchange = True
+    step()
+    seconds, _ = fenced(step, args.steps)
+    compute_only = reduce_max([seconds])[0] / max(1, args.steps)
+    order.skip_exchange = False
     result = None
     if rank == 0:
       valid = specmod.valid_cells(spec, dims, args.iterate)
@@ -465,6 +558,10 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
                       exchange_every=plan.exchange, exchanges_per_step=exchanges,
                       exchange_ms_per_step=exchange_ms,
                       exchange_overlapped=overlap,
+                      exchange_choice='given' if table is None else
+                      'measured (fastest of exchange_candidates_ms)',
+                      exchange_candidates_ms=table or [],
+                      compute_only_ms_per_step=compute_only * 1e3,
                       ghost_rows=[plan.exchange * r_lo, plan.exchange * r_hi],
                       super_step_schedule=schedule_text(sched),
                       valid_cell_updates=valid, nominal_cell_updates=nominal,

@@ -123,3 +123,51 @@ def test_slab_bounds_and_plan():
   bands, interior = sdist.band_plan(first, 20)
   assert bands == [(2048 - 48 - 20, 2048 + 20, True, True)]
   assert interior == (0, 2048 - 48 + 20, False, True)
+
+
+def test_exchange_candidates():
+  # 1, 2, 4, 8 x the deepest kernel, within the thinnest slab and the iteration count
+  assert sdist.exchange_candidates(2048, 1, 24, 1000) == [24, 48, 96, 192]
+  assert sdist.exchange_candidates(8192, 1, 24, 100) == [24, 48, 96, 100]
+  assert sdist.exchange_candidates(64, 1, 4, 200) == [4, 8, 16, 32]
+  assert sdist.exchange_candidates(64, 2, 12, 200) == [12, 24, 32]     # 64 rows / reach 2
+  assert sdist.exchange_candidates(5, 1, 24, 1000) == [5]
+  assert sdist.exchange_candidates(2048, 1, 1, 1) == [1]
+
+
+def test_choose_exchange_takes_the_fastest_row_of_the_slowest_ranks():
+  pairs = [(24, False), (24, True), (48, False), (48, True)]
+  seconds = {(24, False): 0.031, (24, True): 0.034, (48, False): 0.029, (48, True): 0.030}
+  # (a second rank that is slower on the locally fastest pair)
+  other = {(24, False): 0.030, (24, True): 0.030, (48, False): 0.040, (48, True): 0.0305}
+  table, chosen = sdist.choose_exchange(
+      pairs, lambda e, o: seconds[(e, o)],
+      lambda mine: [max(m, other[p]) for m, p in zip(mine, pairs)])
+  assert [(r['exchange'], r['overlapped']) for r in table] == pairs
+  assert [round(r['ms'], 3) for r in table] == [31.0, 34.0, 40.0, 30.5]
+  assert (chosen['exchange'], chosen['overlapped']) == (48, True)
+  assert chosen['ms'] == min(r['ms'] for r in table)
+
+
+def test_all_ranks_choose_the_same_exchange(tmp_path):
+  """Two gloo ranks whose own step times rank the candidates differently: both must end
+  with the table of the slower rank per candidate and the same choice (a rank that
+  picked another exchange period would wait for messages nobody sends)."""
+  import json
+  world = 2
+  # candidates: E = 24, 48, 96, 192, each serial and overlapped
+  times = [[9.0, 9.5, 8.0, 8.4, 7.0, 7.6, 7.4, 7.9],      # rank 0 likes (96, serial)
+           [9.1, 9.2, 7.9, 7.5, 8.8, 7.7, 7.2, 7.3]]      # rank 1 likes (192, serial)
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()),
+             WORLD_SIZE=str(world), OMP_NUM_THREADS='1')
+  procs = [subprocess.Popen(
+      [sys.executable, os.path.join(ROOT, 'tests', 'choose_worker.py'), json.dumps(times),
+       str(tmp_path)], env=dict(env, RANK=str(rank), LOCAL_RANK=str(rank)))
+           for rank in range(world)]
+  for p in procs:
+    assert p.wait(timeout=120) == 0
+  got = [json.load(open(os.path.join(tmp_path, 'choice%d.json' % r))) for r in range(world)]
+  assert got[0] == got[1]
+  slowest = [max(a, b) * 1e3 for a, b in zip(*times)]
+  assert [r['ms'] for r in got[0]['table']] == pytest.approx(slowest)
+  assert (got[0]['chosen']['exchange'], got[0]['chosen']['overlapped']) == (192, False)

@@ -501,6 +501,61 @@ def test_full_size_cfg5_jacobi3d_512_x200_and_cfg3_blur_16384():
   assert np.array_equal(got[sl], want[sl])
 
 
+@pytest.mark.parametrize('app,dims,iterate', [('jacobi2d', [500, 300], 6),
+                                              ('blur', [700, 300], 1)])
+def test_generated_python_host_module_runs_as_the_readme_says(tmp_path, app, dims, iterate):
+  """What `sodac --hip DIR` writes, RUN: `python DIR/<app>.py DIR/<app>.hsaco W H` as a
+  child process (the README's quick start; the reference's test-bench, README.md:76-91,
+  host.py:984-1167) says PASS with the reference's two timing lines, and the module's
+  `<app>(inputs..., outputs..., blob)` (host.py:931-945) on caller-owned arrays equals
+  the oracle on the valid box and leaves every other cell of the output alone."""
+  import importlib.util
+  import subprocess
+  import sys
+  from conftest import ROOT
+  pkg = os.path.join(ROOT, 'soda-compiler_amd')
+  out = tmp_path / 'out'
+  subprocess.check_call([sys.executable, os.path.join(pkg, 'sodac'),
+                         gpu_util.sample_path(app), '--iterate', str(iterate),
+                         '--hip', str(out)])
+  module, blob = out / (app + '.py'), out / (app + '.hsaco')
+  for name in (app + '.py', app + '.hsaco', app + '_kernel.hip', app + '.h',
+               app + '_host.cpp'):
+    assert (out / name).exists(), name
+  env = dict(os.environ, PYTHONPATH=os.pathsep.join(
+      [pkg] + [p for p in os.environ.get('PYTHONPATH', '').split(os.pathsep) if p]))
+  r = subprocess.run([sys.executable, str(module), str(blob)] + [str(d) for d in dims],
+                     capture_output=True, text=True, env=env, timeout=600)
+  assert r.returncode == 0, r.stderr[-2000:]
+  assert 'INFO: PASS!' in r.stderr
+  assert 'Kernel execution time:' in r.stdout and 'Kernel throughput:' in r.stdout
+  # wrong argument count: the usage line and exit code 1 (README.md:79-83)
+  r = subprocess.run([sys.executable, str(module), str(blob)], capture_output=True,
+                     text=True, env=env, timeout=600)
+  assert r.returncode == 1 and 'Usage:' in r.stderr
+  # the module imported, its entry point on the caller's arrays
+  spec_ = importlib.util.spec_from_file_location('generated_' + app, str(module))
+  generated = importlib.util.module_from_spec(spec_)
+  spec_.loader.exec_module(generated)
+  assert generated.ITERATE == iterate
+  spec = gpu_util.load_spec(app, iterate=iterate)
+  assert generated.SPEC == json.loads(json.dumps(spec))
+  shape = tuple(reversed(dims))
+  inputs = gpu_util.random_inputs(spec, shape)
+  marker = 7
+  outputs = [np.full(shape, marker, dtype=inputs[0].dtype)]
+  assert getattr(generated, app)(*inputs, *outputs, str(blob)) == 0
+  orc = gpu_util.make_oracle(spec)
+  want = orc.run(inputs, iterate=iterate)[spec['outputs'][0]]
+  sl = orc.valid_slices(tuple(dims), iterate)
+  assert want[sl].size > 0 and np.array_equal(outputs[0][sl], want[sl])
+  outside = np.ones(shape, dtype=bool)
+  outside[sl] = False
+  assert (outputs[0][outside] == marker).all()
+  # and the module's own <app>_test
+  assert getattr(generated, app + '_test')(str(blob), dims + [0] * (4 - len(dims))) == 0
+
+
 @pytest.mark.parametrize('app,dims,iterate', [
     ('jacobi2d', [500, 300], '12'), ('blur', [2000, 100], '1'),
     ('denoise2d', [300, 200], '1'), ('heat3d', [60, 50, 40], '3')])
@@ -1231,6 +1286,18 @@ def test_bench_py_as_the_driver_launches_it_for_two_gpus():
   assert c['dims'] == [4096, 3000] and c['iterate'] == 120
   assert c['exchanges_per_step'] >= 1 and c['exchange_every'] >= 1
   assert c['ghost_rows'] == [c['exchange_every'], c['exchange_every']]
+  # the exchange period and the order (serial / overlapped) are the fastest of the
+  # candidates timed during warm-up, and the table is on the line
+  table = c['exchange_candidates_ms']
+  assert c['exchange_choice'].startswith('measured')
+  assert sorted({r['exchange'] for r in table}) == [24, 48, 96, 120]
+  assert len(table) == 8 and all(r['ms'] > 0 for r in table)
+  assert {r['overlapped'] for r in table} == {False, True}
+  best = min(table, key=lambda r: r['ms'])
+  assert (c['exchange_every'], c['exchange_overlapped']) == (best['exchange'],
+                                                             best['overlapped'])
+  # the same steps without the exchanges: never (much) slower than with them
+  assert 0 < c['compute_only_ms_per_step'] < 1.25 * d['ms_per_step']
   # whole-job throughput on VALID updates of the whole grid, both ranks' rows
   spec = gpu_util.load_spec('jacobi2d', iterate=120)
   from soda_hip.codegen import spec as specmod

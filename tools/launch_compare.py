@@ -39,6 +39,11 @@ app, n, iterate = sys.argv[1:4]
 runs = []
 for variant in sys.argv[4:]:
   env = dict(os.environ, SODA_HIP_TUNING='1', SODA_HIP_LAUNCH_TRACE='1')
+  # `env:NAME=VALUE` entries of a variant are environment variables of ITS run
+  # (e.g. env:SODA_HIP_PREFER=k4b), the rest are generator options
+  parts = [kv for kv in variant.split(',') if kv]
+  env.update(kv[4:].split('=', 1) for kv in parts if kv.startswith('env:'))
+  variant = ','.join(kv for kv in parts if not kv.startswith('env:'))
   p = subprocess.run([sys.executable, __file__, '--child', app, n, iterate, variant],
                      env=env, capture_output=True, text=True)
   launches = [(m.group(2), float(m.group(3)), float(m.group(4)), m.group(5),
@@ -49,10 +54,11 @@ for variant in sys.argv[4:]:
   if not launches:
     print(variant, 'FAILED', p.stderr[-400:])
     continue
-  runs.append((variant, launches, float(total.group(1))))
+  label = ','.join(parts)
+  runs.append((label, launches, float(total.group(1))))
   print('%-40s %d launches  sum of fastest %.1f us  sweep %.1f us' % (
-      variant, len(launches), sum(l[1] for l in launches), float(total.group(1))))
-if len(runs) > 1 and len({len(r[1]) for r in runs}) == 1:
+      label, len(launches), sum(l[1] for l in launches), float(total.group(1))))
+if runs and len({len(r[1]) for r in runs}) == 1:
   print('%3s  %-18s' % ('#', 'box') + ''.join('  %-32s' % r[0][:32] for r in runs))
   best_sum = 0.0
   for i in range(len(runs[0][1])):
