@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SODA_HIP_ABI_VERSION 4
+#define SODA_HIP_ABI_VERSION 5
 #define SODA_HIP_MAX_DIMS 4
 #define SODA_HIP_MAX_TENSORS 16 /* inputs + stages of one program */
 #define SODA_HIP_MAX_IO 8
@@ -184,6 +184,21 @@ typedef struct soda_hip_kernel {
                          of the x-fastest tile order (XCD L mod 8 takes a RUN of
                          consecutive tiles); param[1] = 1 | 1 << 16, param[2] =
                          (tiles along x) | (along y) << 16 */
+  /* (ABI 5) */
+  int32_t stream_wgs_per_cu; /* N > 0: a launch whose box (inputs + outputs) does not
+                         fit the Infinity Cache keeps at most N workgroups of this kernel
+                         on a CU (the launcher asks for dynamic LDS the kernel never
+                         touches) and walks correspondingly longer chunks: memory-bound
+                         kernels move more bytes per second when the chip streams a few
+                         dozen row ranges than when it streams hundreds (tools/copyceil.hip;
+                         with the seam-free depth-1 strips: jacobi2d 16384^2 -4 %, sobel2d
+                         -6 % under the bench protocol).  0 = no cap */
+  int32_t fade_lo_mib;  /* footprints (MiB of the launch's box, inputs + outputs) between */
+  int32_t fade_hi_mib;  /* which the HBM term of the price (stream_gbps) fades in: below
+                         fade_lo the arrays live in the Infinity Cache and a step costs
+                         step_ns_*, above fade_hi the kernel streams.  Part of the
+                         kernel's calibration record (tools/calibrate.py); 0, 0 = the
+                         defaults 128 and 512 */
 } soda_hip_kernel;
 
 /* By-value argument of every generated kernel. */

@@ -272,8 +272,14 @@ const double kModelLaunchUs = 2.0;
 // arrays several times its size (jacobi3d, one-level-per-wavefront kernel: 1.63 us per
 // step at 304^3 = 215 MiB in + out, the step time of a cache-resident array; 2.03 us at
 // 400^3 = 488 MiB; 2.41 us at 512^3).
-const double kCacheResidentBytes = 128.0 * 1024 * 1024;
-const double kStreamingBytes = 512.0 * 1024 * 1024;
+// The two footprints are part of the kernel's calibration record (soda_hip_kernel.
+// fade_lo_mib / fade_hi_mib, tools/calibrate.py); these are the defaults of kernels
+// that carry none.
+const double kCacheResidentMiB = 128.0;
+const double kStreamingMiB = 512.0;
+// beyond this a launch's box does not fit the 256 MiB Infinity Cache (the kernels' own
+// non-temporal paths switch at the same figure: kernel_common.NT_STREAMING_BYTES)
+const double kBeyondCacheBytes = 288.0 * 1024 * 1024;
 
 double step_seconds(const soda_hip_plan* plan, int k, double blocks, double footprint = 0) {
   const soda_hip_kernel& desc = plan->kernels[k];
@@ -284,9 +290,12 @@ double step_seconds(const soda_hip_plan* plan, int k, double blocks, double foot
   if (desc.step_ns_full > 0 && desc.step_ns_one > 0) {
     const double share = full > 1 ? (per_cu - 1) / (full - 1) : 1.0;
     double t = (desc.step_ns_one + (desc.step_ns_full - desc.step_ns_one) * share) * 1e-9;
-    if (desc.stream_gbps > 0 && desc.step_bytes > 0 && footprint > kCacheResidentBytes) {
-      const double weight = std::min(1.0, (footprint - kCacheResidentBytes) /
-                                              (kStreamingBytes - kCacheResidentBytes));
+    const double mib = 1024.0 * 1024.0;
+    const double fade_lo = (desc.fade_lo_mib > 0 ? desc.fade_lo_mib : kCacheResidentMiB) * mib;
+    const double fade_hi = std::max(fade_lo + mib,
+        (desc.fade_hi_mib > 0 ? desc.fade_hi_mib : kStreamingMiB) * mib);
+    if (desc.stream_gbps > 0 && desc.step_bytes > 0 && footprint > fade_lo) {
+      const double weight = std::min(1.0, (footprint - fade_lo) / (fade_hi - fade_lo));
       t = std::max(t, weight * std::min(blocks, full * cus) * desc.step_bytes /
                           (desc.stream_gbps * 1e9));
     }
@@ -309,10 +318,13 @@ double footprint_of(const soda_hip_plan* plan, const soda_hip_args& args) {
   return footprint;
 }
 
+// workgroups per CU a streaming launch of kernel k is capped at (0 = no cap):
+// soda_hip_kernel.stream_wgs_per_cu for boxes beyond the Infinity Cache
+// (tuning: SODA_HIP_WGS_PER_CU = N for every streaming kernel, -1 = never)
 int streaming_cap(const soda_hip_plan* plan, int k, double footprint) {
-  (void)k;
-  (void)footprint;
-  return plan->wgs_per_cu_cap;
+  if (plan->wgs_per_cu_cap != 0) return std::max(0, plan->wgs_per_cu_cap);
+  if (footprint <= kBeyondCacheBytes) return 0;
+  return std::max(0, (int)plan->kernels[k].stream_wgs_per_cu);
 }
 
 int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,

@@ -62,6 +62,9 @@ WAVE_PIPELINE_MIN_DEPTH = 4
 ALIGN_FULL_MAX_DEPTH = 2
 # ... and their stores bypass the caches on arrays beyond the Infinity Cache
 NT_AUTO_MAX_DEPTH_2D = 2
+# rows a wavefront of the seam-free depth-1 form keeps in flight (16384^2 with two
+# workgroups per CU, 3 / 6 / 9 rows: jacobi2d 419 / 414 / 415 us, sobel2d 270 / 253 / 242)
+EXACT_PREFETCH = 6
 # 3-D: depths beyond the single-wave form, built wave-pipelined (kernel_stream3d_wp)
 DEEP_3D_DEPTHS = (4,)
 BLOCK_3D_SHALLOW_DEPTHS = (1, 2)
@@ -79,10 +82,9 @@ BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300, nt=4, mask_loads=1
 # prefetch registers) where the program's edge rows leave the LDS for it, else one
 # plane ahead in registers.  Per depth-4 launch inside the 512^3 array of cfg5 (same
 # chunking): box 496 242 vs 247 us, 456 205 vs 219, 416 152 vs 166, 352 117 vs 130,
-# 256 53 vs 74; heat3d 512^3 x20, block form alone: 1.94 vs 1.96 ms, with the
-# arithmetic as a hand-ordered instruction stream (kernel_asm; pays for programs
-# above PACKED_3D_LIGHT_WEIGHT only) 1.83 vs 1.90 ms (profiles/r03_blk_variants.txt);
-# packed pair-rows, which the ring's freed registers make room for, beat that.
+# 256 53 vs 74; heat3d 512^3 x20, block form alone: 1.94 vs 1.96 ms
+# (profiles/r03_blk_variants.txt); the ring's freed registers make room for packed
+# pair-rows in heavy programs.
 # mask_loads: ragged tiles fetch only what a stored cell depends on (the buffer form of the
 # LDS-direct load; cfg5 per launch: box 424 161 -> 157 us, 400 140 -> 135, 368 128 -> 120,
 # 360 118 -> 108; boxes that fill their tiles unchanged; the sweep -1.5 %)
@@ -105,8 +107,7 @@ ALIGN_FULL_MAX_WEIGHT = 40
 # generator options of the fused 2-D forms that `generate` passes through:
 # those both forms understand, and those only the wave-pipelined form has
 SHARED_2D_OPTIONS = ('skip_fill', 'vgpr_budget', 'max_period', 'align', 'waves_per_eu')
-WP_ONLY_OPTIONS = ('pairs', 'ring', 'dppadd', 'split', 'sync', 'ringpk', 'fast_store',
-                   'prio', 'rotate', 'ntstore', 'ntload')
+WP_ONLY_OPTIONS = ('pairs', 'ring', 'split', 'prio')
 
 HIPCC_FLAGS = ['-x', 'hip', '--offload-arch=gfx950', '--cuda-device-only',
                '--no-gpu-bundle-output', '-O3', '-ffp-contract=off',
@@ -242,7 +243,8 @@ WP_STEP_FIXED_CYCLES = 640
 
 CALIBRATION_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)),
                                 'calibration.json')
-CALIBRATED_FIELDS = ('step_ns_full', 'step_ns_one', 'stream_gbps')
+CALIBRATED_FIELDS = ('step_ns_full', 'step_ns_one', 'stream_gbps', 'fade_lo_mib',
+                     'fade_hi_mib')
 _calibration = None
 
 
@@ -373,40 +375,30 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
             depth <= ALIGN_FULL_MAX_DEPTH and
             arithmetic_weight(spec) <= ALIGN_FULL_MAX_WEIGHT) else 'none'
       single = piped = None
-      k1 = {k[3:]: v for k, v in fused_options.items() if k.startswith('k1_')}
-      if depth == 1 and k1.get('ring'):
-        # depth 1 through the LDS input ring: one wavefront per strip, rows arrive
-        # by LDS-direct loads (no prefetch registers), counted waits, one decision
-        # per strip about ragged stores (kernel_stream2d_wp with a single group)
-        try:
-          k1.setdefault('groups', 1)
-          k1.setdefault('vgpr_budget', 250)
-          piped = kernel_stream2d_wp.emit(spec, 1, **dict(common, **k1))
-        except kernel_stream2d.NotFusable as e:
-          notes.append('depth 1 not through the ring: %s' % e)
-      if piped is not None:
-        pass
-      elif groups <= 1 or depth < WAVE_PIPELINE_MIN_DEPTH or groups == -1:
+      if groups <= 1 or depth < WAVE_PIPELINE_MIN_DEPTH or groups == -1:
         # the memory-bound depths store around the caches when a launch's box
         # does not fit the Infinity Cache (kernel_stream2d.emit: nontemporal)
         options = dict({'nontemporal': 4} if depth <= NT_AUTO_MAX_DEPTH_2D else {},
                        **{k: v for k, v in fused_options.items()
-                          if k not in WP_ONLY_OPTIONS and not k.startswith('k1_') and
-                          k != 'nt'})
+                          if k not in WP_ONLY_OPTIONS and k != 'nt'})
         # ... and where no STAGE is read across lanes (depth 1 of the samples) their
         # strips do not overlap at all (align='exact': whole 128-byte lines in and
         # out, the seam columns from one extra vector load per row and side)
         aligns = ['exact', 'full'] if common.get('align') == 'full' else \
             [options.pop('align', None) or common['align']]
         for k, how in enumerate(aligns):
+          shape = dict(common, align=how)
+          if how == 'exact' and prefetch is None:
+            # six rows in flight per wavefront (two workgroups per CU on the arrays
+            # that matter, soda_hip_kernel.stream_wgs_per_cu)
+            shape['prefetch'] = EXACT_PREFETCH
           try:
-            single = kernel_stream2d.emit(spec, depth, **dict(common, align=how),
-                                          **options)
+            single = kernel_stream2d.emit(spec, depth, **shape, **options)
             break
           except kernel_stream2d.NotFusable as e:
             if k == len(aligns) - 1:
               notes.append('depth %d not fused: %s' % (depth, e))
-      want_piped = piped is None and depth >= WAVE_PIPELINE_MIN_DEPTH and (
+      want_piped = depth >= WAVE_PIPELINE_MIN_DEPTH and (
           groups > 1 or (groups == -1 and (
               single is None or single[1]['est_vgprs'] > AUTO_WP_VGPRS or
               (depth >= PACKED_FROM_DEPTH and kernel_stream2d_wp.packable(spec)))))
@@ -425,9 +417,6 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
           # 16384^2: 597 us against 627 us for two 256-column strips, pairs=1)
           options.setdefault('pairs', 0 if not kernel_stream2d_wp.packable(spec)
                              else 2 if options.get('ring') else 1)
-          # pairs=1: lane-crossing operands as scalar DPP adds (22 instead of 24
-          # VALU instructions per jacobi2d level-row: depth 16 627 -> 610 us)
-          options.setdefault('dppadd', int(options['pairs'] == 1))
           if depth > PACKED_DEEP_DEPTH and options['pairs'] == 2:
             # 5-6 levels per wavefront: three workgroups per CU (168 VGPRs;
             # depth 24 left alone takes 174 = two per CU: 34.1 vs 33.2 us per
@@ -450,10 +439,10 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
             piped = kernel_stream2d_wp.emit(
                 spec, depth, groups=AUTO_WP_GROUPS, waves_per_eu=4, **common,
                 **dict(options, ring=2 * AUTO_WP_RING, max_period=2 * AUTO_WP_RING))
-          elif squeeze and not options.get('pairs') == 2 and not options.get('dppadd'):
-            # two-strip form without scalar DPP adds: let the compiler spill them
-            # (jacobi2d depth 16: 150 -> 128 VGPRs, 12 spilled, +1.6 %; with
-            # scalar DPP adds the cap spills 45 and loses 60 %: not then)
+          elif squeeze and not options.get('pairs'):
+            # the scalar form: let the compiler spill the few registers over the cap
+            # (not the two-strip packed form: its scalar DPP adds then spill 45
+            # registers and lose 60 %)
             piped = kernel_stream2d_wp.emit(
                 spec, depth, groups=AUTO_WP_GROUPS, waves_per_eu=4, **common,
                 **options)
@@ -530,12 +519,13 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
           # NEXT TO the wave-pipelined kernel and the run-time picks per launch
           given = prefixed_options(fused_options, 'blk_', kernel_stream3d_blk.emit)
           heavy = arithmetic_weight(spec) > PACKED_3D_LIGHT_WEIGHT
-          ring_forms = [dict(BLOCK_3D_RING_OPTIONS, asm_sched=int(heavy))]
-          if heavy and kernel_stream2d_wp.packable(spec) and 'asm_sched' not in given:
+          ring_forms = [dict(BLOCK_3D_RING_OPTIONS)]
+          if heavy and kernel_stream2d_wp.packable(spec):
             # heavy plain-float programs: packed pair-rows first (heat3d 512^3 x20,
-            # block form alone, clocks warm: 1.76 ms plain, 1.49 hand-ordered, 1.42
-            # packed - 13.2 k instead of 22.6 k VALU instructions per unrolled loop,
-            # 254 VGPRs without spills now that the ring took the prefetch registers)
+            # block form alone, clocks warm: 1.76 ms plain, 1.42 packed - 13.2 k instead
+            # of 22.6 k VALU instructions per unrolled loop, 254 VGPRs without spills
+            # now that the ring took the prefetch registers; a hand-ordered scalar
+            # instruction stream, round 3's kernel_asm, reached 1.49 and is gone)
             # (and exact store ranges: whole 64-byte pieces cost this kernel 3 %,
             # heat3d 512^3 x20 1.37 -> 1.41 ms, where they gain jacobi3d's 2 %)
             ring_forms.insert(0, dict(BLOCK_3D_RING_OPTIONS, pairs=1, wide_stores=0))
@@ -544,7 +534,6 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
           try:
             for k, base in enumerate(attempts):
               options = dict(base)
-              options.setdefault('asm_sched', int(base.get('ring', 0) > 0 and heavy))
               options.update(given)
               try:
                 ftext, entry = kernel_stream3d_blk.emit(spec, depth, **options)

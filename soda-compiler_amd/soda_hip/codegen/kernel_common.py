@@ -12,7 +12,7 @@ import re
 
 from . import spec as specmod
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # A launch whose box (inputs + outputs) is larger than this streams: nothing it writes
 # is still cached when the next launch reads it, and its stores go out non-temporal
@@ -229,14 +229,6 @@ template <typename T, bool BELOW> DEV T lane_neighbour(T v) {
                                                        : dpp_from_above(w)));
   }
 }
-// the same exchange through the LDS crossbar (ds_bpermute_b32): no VALU issue
-// slot, but LDS-pipe latency that has to be covered by other work
-template <typename T, bool BELOW> DEV T lane_neighbour_bp(T v) {
-  static_assert(sizeof(T) == 4, "32-bit values only");
-  const int src = ((lane_id() + (BELOW ? -1 : 1)) & 63) << 2;
-  return __builtin_bit_cast(T, __builtin_amdgcn_ds_bpermute(
-      src, __builtin_bit_cast(int, v)));
-}
 // Rows across the two 32-lane halves of a wavefront (v_permlane32_swap): `first`
 // and `last` are a lane's first and last tile rows.  The upper half receives in
 // `above` the lower half's `last` (the row above its first one), the lower half
@@ -284,8 +276,6 @@ template <typename T, bool BELOW> DEV T lane_neighbour_or(T v, T edge) {
 }
 template <typename T> DEV T from_lane_below_or(T v, T edge) { return lane_neighbour_or<T, true>(v, edge); }
 template <typename T> DEV T from_lane_above_or(T v, T edge) { return lane_neighbour_or<T, false>(v, edge); }
-template <typename T> DEV T from_lane_below_bp(T v) { return lane_neighbour_bp<T, true>(v); }
-template <typename T> DEV T from_lane_above_bp(T v) { return lane_neighbour_bp<T, false>(v); }
 template <typename T> DEV T from_lane_below(T v) { return lane_neighbour<T, true>(v); }
 template <typename T> DEV T from_lane_above(T v) { return lane_neighbour<T, false>(v); }
 // Packed pairs (kernel_stream2d_wp, pairs=1): the neighbour lane's pair as two

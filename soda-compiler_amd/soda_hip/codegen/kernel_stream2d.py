@@ -132,10 +132,7 @@ def geometry(spec, depth, cols, chunk_rows, align='none'):
   line -= line % cols
   halo_lo = -(-lo[0] // cols) * cols      # padded up to whole vectors
   halo_hi = -(-hi[0] // cols) * cols
-  if align in ('store64', 'full64'):   # ... on a 64-byte piece (what a partial write
-    line = max(cols, 64 // elem)       # is counted in)
-    line -= line % cols
-  if align in ('full', 'full64'):
+  if align == 'full':
     halo_lo = -(-lo[0] // line) * line
   if align == 'exact':
     halo_lo = halo_hi = 0
@@ -143,11 +140,11 @@ def geometry(spec, depth, cols, chunk_rows, align='none'):
   origin_align = cols
   if align == 'exact':
     origin_align = line
-  elif align in ('store', 'store64', 'full', 'full64') and w_out >= line:
+  elif align in ('store', 'full') and w_out >= line:
     w_out -= w_out % line
     halo_hi = LANES * cols - halo_lo - w_out
     origin_align = line
-  elif align not in ('none', 'store', 'store64', 'full', 'full64', 'exact'):
+  elif align not in ('none', 'store', 'full', 'exact'):
     raise ValueError('align: %r' % (align,))
   if w_out < cols:
     raise NotFusable('depth %d leaves no output columns in a strip' % depth)
@@ -161,8 +158,8 @@ def kernel_name(spec, depth):
 
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
-         vgpr_budget=244, waves_per_eu=0, bpermute=0, skip_fill=1, xcd_remap=0, nontemporal=0,
-         align='none', steady=None):
+         vgpr_budget=244, waves_per_eu=0, skip_fill=1, nontemporal=0, align='none',
+         steady=None, stage_edges=0, stream_wgs=None):
   """Returns (text, kernel table entry) for one fused depth.
 
   steady (default: on for depth <= 2, the memory-bound kernels): the rows of a chunk
@@ -187,12 +184,17 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
     cols = max(1, 16 // elem)
   insts, final = build_pipeline(spec, depth, prefetch)
   geo = geometry(spec, depth, cols, chunk_rows, align)
+  C = cols
   for inst in insts:
     for src, rel, _ in inst.reads:
       if abs(rel[0]) > cols:
         raise NotFusable('x offset %d exceeds the %d columns a lane holds'
                          % (rel[0], cols))
   exact = align == 'exact'
+  # the steady-state loop without any branch (round 4): the row's store is a raw buffer
+  # store whose lane offset is out of range in lanes that store nothing (halo lanes of
+  # overlapping strips), a scheduling fence per row, loaded rows kept packed - see emit_body
+  flat = steady and C * elem in (4, 8, 16)
   for inst in insts:
     inst.edges = 0      # columns beyond the strip, per side, that readers ask for
   if exact:
@@ -205,6 +207,11 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
       for src, rel, _ in inst.reads:
         src.edges = max(src.edges, abs(rel[0]))
       if inst.edges and inst.stage is not None:
+        if not stage_edges:
+          # (blur: blur_y reads blur_x across lanes.  Computing blur_x beyond the strip
+          # works - bit-exact, `stage_edges=1` - and is no faster than overlapping
+          # strips: 16384^2 222-242 us against 220; so such programs keep the overlap)
+          raise NotFusable('seam-free strips: stage %s is read across lanes' % inst.tensor)
         for src, rel, _ in inst.reads:
           if rel[0]:
             raise NotFusable('seam-free strips: stage %s is read across lanes and reads '
@@ -303,11 +310,13 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
       T_out, T_out, index[out_name]))
   if steady:
     emit_line('  const bool st_full = x >= st_lo && x + %d <= st_hi;' % C)
+  if flat:
+    emit_line('  const unsigned st_voff = st_full ? (unsigned)(x * %d) : 0xfffffff0u;' % elem)
   for inst in insts:
     # seam-free strips: a loaded row stays the VECTOR it arrived as until its cells are
     # used (sub-dword elements are unpacked there; unpacked at the load - behind the
     # scheduling fence of its step - every row would be waited for as soon as issued)
-    inst.packed = exact and inst.stage is None and inst.c_type == in_type
+    inst.packed = flat and inst.stage is None and inst.c_type == in_type
     if inst.keep and inst.packed:
       emit_line('  %s %s[%d];' % (vec_in, inst.ident, inst.keep))
     elif inst.keep:
@@ -354,7 +363,6 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
     j = c + rel[0]
     if 0 <= j < C:
       return '%s[%d]' % (row, j)
-    suffix = '_bp' if bpermute else ''
     if exact:       # the first / last lane take the column from the strip's edge loads
       assert src.edges
       if j < 0:
@@ -363,8 +371,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
       return 'from_lane_above_or(%s[%d], edge_hi_%s[%d][%d])' % (
           row, j - C, src.ident, slot(src, u, back), j - C)
     if j < 0:
-      return 'from_lane_below%s(%s[%d])' % (suffix, row, C + j)
-    return 'from_lane_above%s(%s[%d])' % (suffix, row, j - C)
+      return 'from_lane_below(%s[%d])' % (row, C + j)
+    return 'from_lane_above(%s[%d])' % (row, j - C)
 
   def emit_body(guarded, calm=False):
     """calm: the steady-state copy - every row loaded lies inside the array, every
@@ -437,8 +445,24 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
           emit_line('        const i64 y = head + %d;' % (u - L))
           emit_line('        %s{' % ('' if calm else 'if (y >= y0 && y < y1) '))
           emit_line('          %s* q = g_out + y * W + x;' % T_out)
-          if calm and exact:      # !RAGGED: every lane of the strip stores all its columns
-            emit_line('          if (!RAGGED || (x >= st_lo && x + %d <= st_hi)) {' % C)
+          if calm and flat:
+            # !RAGGED (decided once per strip): a lane stores its whole vector or nothing -
+            # ONE raw buffer store on the row, the lane's offset out of range where it
+            # stores nothing: no branch, so the compiler's waits in this loop are exact
+            # counts (behind a branch, and behind __builtin_nontemporal_store, it waits
+            # for every access in flight: vmcnt(0) once per row or per trip)
+            bits = {4: ('b32', 'unsigned'), 8: ('b64', 'soda_u2'),
+                    16: ('b128', 'soda_u4')}[vec_bytes]
+            emit_line('          if (!RAGGED) {')
+            emit_line('            %s v;' % vec_out)
+            for c in range(C):
+              emit_line('            v[%d] = out_row[%d];' % (c, c))
+            emit_line('            __builtin_amdgcn_raw_buffer_store_%s(__builtin_bit_cast(%s, v), '
+                      '__builtin_amdgcn_make_buffer_rsrc((void*)(g_out + y * W), 0, '
+                      '(int)(W * %d), 0x27000), st_voff, 0, %s);' % (
+                          bits[0], bits[1], elem, 'NT ? 2 : 0' if nt_auto else
+                          '2' if nontemporal & 2 else '0'))
+            emit_line('          } else if (x >= st_lo && x + %d <= st_hi) {' % C)
           elif calm:
             emit_line('          if (RAGGED ? (x >= st_lo && x + %d <= st_hi) : st_full) {' % C)
           else:
@@ -446,17 +470,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
           emit_line('            %s v;' % vec_out)
           for c in range(C):
             emit_line('            v[%d] = out_row[%d];' % (c, c))
-          if nt_auto and exact and vec_bytes in (4, 8, 16):
-            # (as a raw buffer store on the row: behind __builtin_nontemporal_store the
-            # compiler waits for EVERY access in flight once per trip of the row loop -
-            # s_waitcnt vmcnt(0) where the plain store has vmcnt(4) - which empties the
-            # pipeline of loads this loop exists for)
-            bits = {4: ('b32', 'unsigned'), 8: ('b64', 'soda_u2'), 16: ('b128', 'soda_u4')}[vec_bytes]
-            emit_line('            if (NT) __builtin_amdgcn_raw_buffer_store_%s(__builtin_bit_cast('
-                      '%s, v), __builtin_amdgcn_make_buffer_rsrc((void*)(g_out + y * W), 0, '
-                      '(int)(W * %d), 0x27000), (unsigned)(x * %d), 0, 2); else *(%s*)q = v;' % (
-                          bits[0], bits[1], elem, elem, vec_out))
-          elif nt_auto:
+          if nt_auto:
             emit_line('            if (NT) __builtin_nontemporal_store(v, (%s*)q); '
                       'else *(%s*)q = v;' % (vec_out, vec_out))
           elif nontemporal & 2:
@@ -473,7 +487,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
         if skip:
           emit_line('      }')
       emit_line('    }')
-      if calm and exact:
+      if calm and flat:
         # a scheduling fence per row: nothing that uses a row moves up across the loads
         # issued after it (a use hoisted to the top of the loop waits for the load
         # issued LAST - vmcnt(0) once per trip - and the pipeline of rows in flight
@@ -512,29 +526,11 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
   emit_line('  const int lane = lane_id();')
   emit_line('  const int wave = __builtin_amdgcn_workitem_id_x() >> 6;')
   emit_line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % geo['origin_align'])
-  if xcd_remap:
-    # Workgroups are dealt round-robin over the 8 XCDs (each with its own L2):
-    # ids b and b+8 share one.  Re-deal them so that every XCD works on a
-    # CONTIGUOUS run of tiles (x fastest): neighbouring strips and chunks, which
-    # re-read each other's halo columns / fill rows, then share an L2.  Pure
-    # speed; any placement is correct.  Bijective for any grid size.
-    # Measured on MI355X (jacobi2d 16384^2 k12/k8, blur k1): within +-1 %, blur
-    # -3 % -- the halo re-reads are a few percent of the traffic and the kernels
-    # are not L2-bound -- so it is OFF by default.
-    emit_line('  const unsigned gx = __builtin_amdgcn_grid_size_x() / %d;'
-              % (WAVES_PER_BLOCK * LANES))
-    emit_line('  const unsigned gy = __builtin_amdgcn_grid_size_y();')
-    emit_line('  const unsigned total = gx * gy;')
-    emit_line('  const unsigned lin = __builtin_amdgcn_workgroup_id_x() + gx * '
-              '__builtin_amdgcn_workgroup_id_y();')
-    emit_line('  const unsigned xcd = lin & 7u, within = lin >> 3;')
-    emit_line('  const unsigned share = total >> 3, extra = total & 7u;')
-    emit_line('  const unsigned tile_id = xcd * share + (xcd < extra ? xcd : extra) '
-              '+ within;')
-    emit_line('  const unsigned block_x = tile_id % gx, block_y = tile_id / gx;')
-  else:
-    emit_line('  const unsigned block_x = __builtin_amdgcn_workgroup_id_x();')
-    emit_line('  const unsigned block_y = __builtin_amdgcn_workgroup_id_y();')
+  # (Re-dealing the workgroups so that every XCD - ids b and b + 8 share one L2 - works
+  # on a contiguous run of tiles was measured: jacobi2d 16384^2 depths 12 / 8 and blur
+  # depth 1 within +-1 %, blur -3 %; the halo re-reads are a few percent of the traffic.)
+  emit_line('  const unsigned block_x = __builtin_amdgcn_workgroup_id_x();')
+  emit_line('  const unsigned block_y = __builtin_amdgcn_workgroup_id_y();')
   emit_line('  const i64 strip = (i64)block_x * %d + wave;' % WAVES_PER_BLOCK)
   emit_line('  const i64 xs = x_origin + strip * %d;' % geo['w_out'])
   emit_line('  if (xs >= a.box_hi[0]) return;')
@@ -555,7 +551,9 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
     else:
       emit_line('  const bool partial = !(x >= st_lo && x + %d <= st_hi) && (%s);' % (
           C, ' || '.join('(x + %d >= st_lo && x + %d < st_hi)' % (c, c) for c in range(C))))
-    emit_line('  const bool ragged = __builtin_amdgcn_ballot_w64(partial) != 0;')
+    # (rows of 4 GiB or more: the branch-free store's 32-bit offsets do not reach)
+    emit_line('  const bool ragged = __builtin_amdgcn_ballot_w64(partial) != 0 || '
+              'a.dims[0] * %d >= 0xfffffff0ll;' % elem)
     emit_line('  if (!interior) %s_strip<false, true>(a, xs, x, y0, y1);' % name)
     emit_line('  else if (ragged) %s_strip<true, true>(a, xs, x, y0, y1);' % name)
     if nt_auto:
@@ -579,7 +577,17 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
                halo=[geo['halo_lo'], geo['halo_hi']], w_out=geo['w_out'],
                steady=int(steady))
   if exact:
+    # seam-free strips: straight-line row loop with counted waits - the kernel that
+    # gains from fewer, longer chunks on arrays beyond the caches (16384^2, single
+    # launches, workgroups per CU uncapped / 4 / 2 / 1: jacobi2d 436 / 436 / 414 / 466 us,
+    # sobel2d 251 / 244 / 253 / 290; under the bench protocol, uncapped against 2:
+    # jacobi2d 0.465 / 0.441 ms, sobel2d 0.258 / 0.257; the overlapping form LOSES with a
+    # cap: sobel2d 0.272 / 0.314 ms; profiles/r04_k1_ab.txt)
     entry['exact'] = 1
+  if stream_wgs is None:
+    stream_wgs = 2 if exact else 0
+  if stream_wgs:
+    entry['stream_wgs_per_cu'] = int(stream_wgs)
   if nontemporal:
     entry['nontemporal'] = int(nontemporal)
   return '\n'.join(o) + '\n', entry

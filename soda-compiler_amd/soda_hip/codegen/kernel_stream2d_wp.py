@@ -163,7 +163,7 @@ def packable(spec):
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
          max_period=12, vgpr_budget=120, skip_fill=1, pairs=0, align='none',
-         ring=0, waves_per_eu=0, dppadd=0, split=None, sync=1, ringpk=1, fast_store=1, prio=None, rotate=0, ntstore=0, ntload=0):
+         ring=0, waves_per_eu=0, split=None, prio=None):
   """Returns (text, kernel table entry).
 
   pairs=2 (needs the ring): ONE strip of 2 x 64 x C columns per wavefront; a
@@ -173,12 +173,15 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   them DPP), but the x halo is paid once per 512 columns instead of per 256
   (jacobi2d depth 16: 480 of 512 columns kept against 448).
 
-  sync=S: one workgroup barrier per S streamed rows instead of one per row; a
-  hand-off slot then holds S rows and arrives S steps after it was produced
-  (S must divide half the rotation period so that slot parity repeats).
+  With pairs=1 the lane-crossing operands stay two scalars so that each shift folds
+  into a scalar add (kernel_common: pk2_shifted; jacobi2d depth 16: 627 -> 610 us).
 
-  dppadd=1 (with pairs): lane-crossing operands stay two scalars so that each
-  shift folds into a scalar add (kernel_common: pk2_shifted).
+  Measured and removed (all bit-exact, none a gain twice): one
+  barrier per 2 or 3 rows instead of one per row (607 vs 602 us per depth-16 launch),
+  wavefront roles rotated per workgroup (549 vs 543), non-temporal ring loads and
+  stores of the deep kernels (+-0.4 % of cfg4), the ring read as two ds_read_b128 plus
+  eight moves instead of four ds_read2_b32 (+0.5 %), per-lane store predicates per row
+  instead of one decision per strip (589 vs 581).
 
   ring=N (a divisor of the rotation period, >= 3): the first wavefront does not
   prefetch input rows into registers; it streams them into an N-slot LDS ring
@@ -219,8 +222,9 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   if isinstance(split, str):
     split = [int(v) for v in split.split('/')]
   everything, per_wave, final = build_groups(spec, depth, 0 if RS else prefetch,
-                                             groups, split=split, sync=sync)
-  S = int(sync)
+                                             groups, split=split)
+  S = 1       # rows per workgroup barrier (and per hand-off slot)
+  dppadd = int(pairs) == 1
   geo = geometry(spec, depth, C, chunk_rows, align)
   if wide:      # the second half adds 64 x C columns, all of them output
     geo['w_out'] += LANES * C
@@ -325,7 +329,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
            'address_space(1))) void*)(g_in + row * W + %s), (__attribute__(('
            'address_space(3))) void*)&in_ring[%d][%d][0], 16, 0, %d);'
            % (('x - lane * %d + %d' % (C, h * LANES * C)) if wide else
-              ('xb' if h else 'x'), slot_index, h, 2 if ntload else 0))
+              ('xb' if h else 'x'), slot_index, h, 0))
     line('        }')
 
   def emit_body(mine, guarded):
@@ -338,7 +342,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
           # row head+u was issued PF rows ago
           line('        __builtin_amdgcn_s_waitcnt(%d);  // vmcnt(%d)'
                % (vmcnt(PF * P), PF * P))
-          if wide and ringpk and C == 4:
+          if wide and C == 4:
             # the four pairs straight from the LDS read (ds_read2_b32) instead of
             # two ds_read_b128 and eight register moves: 0.4-0.7 % per depth-16
             # launch in four paired runs (552 vs 555 us)
@@ -423,16 +427,10 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
           line('          if (y >= y0 && y < y1) {')
           # common case, decided once per strip: no lane's vector straddles an
           # edge of the store range, so a lane stores its whole vector or nothing
-          line('            if (%s) {' % ('!ragged' if fast_store else 'false'))
+          line('            if (!ragged) {')
           for half in range(P):
             sel = '[%d]' % half if pairs else ''
             xv = 'xb' if half else 'x'
-            if ntstore:     # (measured only: tools/tune.py ...,ntstore=1)
-              line('              if (full_%d) { %s v;%s __builtin_nontemporal_store(v, '
-                   '(%s*)(g_out + y * W + %s)); }'
-                   % (half, vec, ''.join(' v[%d] = out_row[%d]%s;' % (c, c, sel)
-                                         for c in range(C)), vec, xv))
-              continue
             line('              if (full_%d) { %s v;%s *(%s*)(g_out + y * W + %s) = v; }'
                  % (half, vec, ''.join(' v[%d] = out_row[%d]%s;' % (c, c, sel)
                                        for c in range(C)), vec, xv))
@@ -550,14 +548,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   line('  __attribute__((shared)) %s in_ring[%d][%d][%d];' % (
       T_in, RS if RS else 1, ring_dims[0], ring_dims[1]))
   line('  const int lane = lane_id();')
-  if rotate:   # which wavefront plays which group differs from workgroup to
-    # workgroup (measured: 549 vs 543 us per depth-16 launch - no gain, off)
-    line('  const int wave = (__builtin_amdgcn_readfirstlane('
-         '__builtin_amdgcn_workitem_id_x() >> 6) + (int)__builtin_amdgcn_workgroup_id_x()'
-         ' + (int)__builtin_amdgcn_workgroup_id_y()) %% %d;' % groups)
-  else:
-    line('  const int wave = __builtin_amdgcn_readfirstlane('
-         '__builtin_amdgcn_workitem_id_x() >> 6);')
+  line('  const int wave = __builtin_amdgcn_readfirstlane('
+       '__builtin_amdgcn_workitem_id_x() >> 6);')
   line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % geo['origin_align'])
   tile_cols = geo['w_out'] * (1 if wide or not pairs else 2)
   line('  const i64 xs = x_origin + (i64)__builtin_amdgcn_workgroup_id_x() * %d;'
@@ -596,5 +588,5 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
                ring=RS, min_extent=[strip_cols, 1] if RS else [0, 0],
                origin_align=geo['origin_align'],
                fill_rows=L + geo['y_lo'], cols=C, prefetch=prefetch, period=period,
-               est_vgprs=est_vgprs, groups=groups, w_out=geo['w_out'], sync=S)
+               est_vgprs=est_vgprs, groups=groups, w_out=geo['w_out'])
   return '\n'.join(o) + '\n', entry

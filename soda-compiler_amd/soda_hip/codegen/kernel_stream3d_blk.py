@@ -37,7 +37,6 @@ between neighbouring PEs are the published edge rows.
 Scope: one input, one output, 4-byte elements, x offsets within C columns,
 y offsets within R rows.
 """
-from . import kernel_asm
 from . import kernel_common
 from . import spec as specmod
 from .kernel_common import builtin_type, cell_assignment, device_expr, tensor_index
@@ -91,11 +90,13 @@ def build_chain(spec, depth, prefetch):
   return insts, final
 
 
+MAX_PERIOD = 12     # longest unrolled rotation of the register windows
+ALIGN_OUT = 16      # cells: output tiles start and end on 64-byte pieces
+
+
 def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
-         max_period=12, vgpr_budget=250, waves_per_eu=0, xcd_tiles=1, ring=0,
-         pairs=0, align_out=16, xcd_runs=1, stamps=0,
-         flat_stores=2, skip_fill=0, fence=1, asm_sched=0, asm_group=4,
-         edge_ahead=1, mask_loads=0, nt=0, skip_bands=0, wide_stores=0):
+         vgpr_budget=250, ring=0, pairs=0, stamps=0, mask_loads=0, nt=0,
+         wide_stores=0):
   """Returns (text, kernel table entry).
 
   `prefetch` = input planes loaded ahead into REGISTERS (R*C VGPRs each);
@@ -115,59 +116,35 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   lane-crossing x-neighbours, are two scalars each (kernel_common: pk2_shifted,
   the DPP shift folded into a v_add_f32_dpp).  Same IEEE operations in the same
   order as the scalar form.
-  `align_out` = N > 1: the tiles' output columns start on multiples of N cells and
-  are a multiple of N wide, so that the row segments two neighbouring workgroups
-  store meet on a 64-byte boundary (N = 16 floats) or a 128-byte line (N = 32).
-  tools/tile3dbench.hip (this kernel's access pattern without the arithmetic,
-  512^3): row segments that start 16 bytes into a line cost a pure copy +41 %
-  (a line shared by two workgroups leaves L2 as masked partial writes), 64 bytes
-  into it +14 %; with 120 of 128 columns kept (segments end anywhere) the copy
-  takes 294 us, with 112 kept 247 us, with 96 (whole lines, one more tile column)
-  266 us.  Misaligned LOADS cost 7 %.
-  `xcd_runs` = 1: each XCD (workgroup id mod 8) takes a RUN of consecutive tiles
-  (x fastest, then y, then z chunks) instead of every eighth one, so that tiles
-  which share halo cells and cache lines run on one L2: the copy 247 -> 236 us.
-  `flat_stores` = 1: the same R store instructions every step, a row or plane that is
-  not to be stored dropped by an out-of-range offset (what the ring form needs for its
-  counted wait).  Loads and stores share one in-order counter (vmcnt); behind stores
-  under branches the compiler must assume that none was issued, so its wait for the
-  prefetched plane (`vmcnt(8)`: only the loads just issued may be outstanding) also
-  waited for the acknowledgement of the stores issued a few hundred cycles earlier.
-  Measured (jacobi3d 512^3): 343 us against 294 us with the branches - the stamped
-  build shows the wavefronts stalled at the ISSUE of the stores (memory back-pressure),
-  and the select per row un-fuses the DPP adds; off.
-  `flat_stores` = 2: no branch inside a step at all - the band function is
-  instantiated for ragged and for full tiles (decided once per workgroup), a lane's
-  part of the store predicate is a loop-invariant offset, and a row's or plane's part
-  is the record count of the row's buffer resource (0 drops the store): scalar selects
-  instead of branches, the same eight store instructions every step.
-  `skip_fill` = 1: a stage instance runs only at the steps whose plane some output
-  plane of the chunk depends on, and input planes beyond the chunk's upper halo are
-  not loaded.  A chunk of n planes walks n + fill steps; without this every level
-  computes (and the loader fetches) at all of them - 4 (n + 13) level-planes where
-  4 n + 12 are needed at depth 4, and 5 of 113 input planes per chunk of 100 read
-  for nothing.  Wave-uniform scalar branches; results are untouched (a skipped plane
-  lies outside every dependency cone).  skip_fill = 2: only the loads.  Measured
-  (jacobi3d, one depth-4 launch): 512^3 277 us without, 318 us with; 400^3 139 / 148 -
-  the branches cut the step's one basic block into pieces the scheduler no longer
-  overlaps; off.
-  `asm_sched` = 1 (plain float programs without division, scalar form): the cells of
-  a level's plane as one interleaved stream of VALU instructions, `asm_group` cells in
-  lock step (kernel_asm.py), instead of C++ statements the scheduler serialises.
-  Bit-exact; measured per 512^3 launch: heat3d (13 operations per cell) 454 -> 386 us,
-  no better than its packed wave-pipelined kernel (380); jacobi3d (7) 257 -> 270: a
-  level's ~112 instructions already issue at the single-wavefront rate (one per ~4.3
-  cycles: tools/blk_stamps.py), the separate DPP moves only add to them.  Off.
-  `edge_ahead` = 1: a level's reads of its neighbours' edge rows (LDS) are issued one
-  part of the step earlier - in front of the previous level's arithmetic (what they
-  read was published before the step's barrier) - so that the round trip runs beside
-  that arithmetic instead of in front of the level's own (with fences the compiler
-  cannot move them there itself); 2: all of them at the start of the step.
-  `fence` = 1: a scheduling fence (`sched_barrier`) between the parts of a step.
-  Without branches (flat_stores = 2) a step is ONE basic block of ~550 instructions
-  and the scheduler's own order was 25 % slower than the same code with fences
-  (348 vs 280 us, found because the STAMPED diagnostic build ran faster than the
-  plain one).
+  Fixed parts of the design (they were options while they were being measured; the A/B
+  figures are in DESIGN.md 4.1d and profiles/r03_blk_variants.txt, r03_blk_stamps.txt):
+  * the tiles' output columns start on multiples of ALIGN_OUT = 16 cells and are a
+    multiple of 16 wide, so that the row segments of neighbouring workgroups meet on
+    64-byte boundaries (tools/tile3dbench.hip, this kernel's access pattern without the
+    arithmetic, 512^3: row segments that start 16 bytes into a line cost a pure copy
+    +41 % - a line shared by two workgroups leaves L2 as masked partial writes - 64
+    bytes into it +14 %; 120 of 128 columns kept 294 us, 112 kept 247 us);
+  * each XCD (workgroup id mod 8) takes a RUN of consecutive tiles (x fastest, then y,
+    then z chunks), so that tiles which share halo cells and cache lines run on one L2
+    (the copy 247 -> 236 us);
+  * no branch inside a step: the band function is instantiated for ragged and for full
+    tiles (decided once per workgroup), a lane's part of the store predicate is a
+    loop-invariant offset, a row's or plane's part the record count of the row's buffer
+    resource (0 drops the store) - the same eight store instructions every step, which
+    is what the ring's counted wait needs (loads and stores share one in-order counter;
+    behind stores under branches the compiler waits for all of them).  Skipping the
+    levels and loads a chunk's fill steps do not need was measured with branches (+14 %:
+    they cut the step's one basic block) and without (nothing); so was ending the
+    wavefronts of bands outside every stored cell's cone (nothing: those launches are
+    bound by memory);
+  * a scheduling fence between the parts of a step (input plane, each stage instance,
+    barrier): left alone, the scheduler's order of the ~550 instructions was 25 % slower;
+  * a level's reads of its neighbours' edge rows (LDS) are issued one part of the step
+    ahead of its arithmetic (register-prefetch form only; the ring form reads them where
+    they are used).
+  A hand-ordered instruction stream for the arithmetic (one `asm` per VALU instruction,
+  cells interleaved) was built and measured twice: it paid only for heavy programs and
+  packed pair-rows beat it there, so it is gone.
   `stamps` = device address of a debug buffer (tools/blk_stamps.py only): the
   wavefront sums the shader cycles (s_memtime) it spends in each part of a step -
   input plane, each stage instance, the barrier - and lane 0 writes the sums there;
@@ -191,10 +168,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   tile's values for them; 2 = only in the launches beyond the Infinity Cache (with the
   non-temporal instantiation).  A partial piece at a box's edge costs a masked write:
   cfg5 -2.5..-6 % under the bench protocol.  2 ships (not for packed pair-rows: heat3d
-  +3 %).
-  `skip_bands` = 1: wavefronts whose band lies outside every stored cell's cone (ragged
-  tiles at the box's y edges) end at once; the barrier counts only live wavefronts.
-  Bit-exact, no gain (those launches are bound by memory); off."""
+  +3 %)."""
   if spec['dim'] != 3:
     raise NotFusable('3-D programs only')
   types = specmod.tensor_c_types(spec)
@@ -217,18 +191,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     raise NotFusable('ring and register prefetch exclude each other')
   insts, final = build_chain(spec, depth, prefetch)
   source = insts[0]
-  # planes of an instance that the chunk's output planes [z0, z1) depend on:
-  # [z0 - need_lo, z1 + need_hi)
-  for inst in insts:
-    inst.need_lo = inst.need_hi = None
-  final.need_lo = final.need_hi = 0
-  for inst in reversed(insts):
-    if inst.need_lo is None:
-      continue
-    for src, rel, _ in inst.reads:
-      lo_need, hi_need = inst.need_lo - rel[2], inst.need_hi + rel[2]
-      src.need_lo = lo_need if src.need_lo is None else max(src.need_lo, lo_need)
-      src.need_hi = hi_need if src.need_hi is None else max(src.need_hi, hi_need)
   rows_per_load = 16 // (C * elem)     # a 16-byte-per-lane load covers this many rows
   if ring and (rows_per_load < 1 or R % rows_per_load):
     raise NotFusable('ring: %d rows per load do not divide %d rows' % (rows_per_load, R))
@@ -238,9 +200,9 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   halo_lo = -(-lo[0] // C) * C
   halo_hi = -(-hi[0] // C) * C
   w_out = LANES * C - halo_lo - halo_hi
-  align_out = max(C, int(align_out))
+  align_out = max(C, ALIGN_OUT)
   if align_out % C:
-    raise NotFusable('align_out must be a multiple of the %d columns a lane holds' % C)
+    raise NotFusable('%d columns a lane do not divide the 64-byte store pieces' % C)
   if w_out >= align_out:
     w_out -= w_out % align_out
   else:
@@ -261,7 +223,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   slots = max([i.age for i in insts]) + 1
   slots = max(2, slots)
   best = None
-  for candidate in range(1, max_period + 1):
+  for candidate in range(1, MAX_PERIOD + 1):
     if max(inst.keep for inst in insts) > candidate or candidate % slots or \
         (ring and candidate % ring):
       continue
@@ -359,7 +321,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     for r in range(R):
       line('  ' + ' '.join('v%d_%d = t%d[%d];' % (r, c, r, c) for c in range(C)))
     line('}')
-  nt_auto = bool(nt & 4) and flat_stores == 2
+  nt_auto = bool(nt & 4)
   stream_expr = ('(a.box_hi[0] - a.box_lo[0]) * (a.box_hi[1] - a.box_lo[1]) * '
                  '(a.box_hi[2] - a.box_lo[2]) * %d > %dll' % (
                      2 * elem, kernel_common.NT_STREAMING_BYTES))
@@ -387,8 +349,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     store_range = [
         '  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];',
         '  const i64 st_hi = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];' % (w_out, w_out)]
-  if flat_stores == 2:
-    line('template <bool RAGGED%s>' % (', bool NT' if nt_auto else ''))
+  line('template <bool RAGGED%s>' % (', bool NT' if nt_auto else ''))
   line('DEV void %s_band(const soda_hip_args& a, const i64 xs, const i64 yb, '
        'const i64 wx, const i64 wy, const i64 z0, const i64 z1, const int wave, '
        'const int lane, %s (*edges)[%d][%d][%d][%d], %s (*in_ring)[%d][%d][%d]) {'
@@ -411,22 +372,18 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('  const bool st_full = x >= st_lo && x + %d <= st_hi;' % C)
   for c in range(C):
     line('  const bool st_col%d = x + %d >= st_lo && x + %d < st_hi;' % (c, c, c))
-  if flat_stores == 2:
-    # no branch inside a step: raggedness is a template parameter, the lane's part of
-    # the store predicate a loop-invariant offset, the row's and the plane's part the
-    # record count of the row's buffer resource (scalar selects)
-    line('  const bool st_ragged = RAGGED;')
-    line('  const unsigned st_voff = st_full ? lane_byte : 0xfffffff0u;')
-    for c in range(C):
-      line('  const unsigned st_voff%d = st_col%d ? lane_byte + %d : 0xfffffff0u;'
-           % (c, c, c * elem))
-    line('  unsigned st_rows = 0;')
-    for r in range(R):
-      line('  if (y_band + %d >= st_ylo && y_band + %d < st_yhi) st_rows |= %du;'
-           % (r, r, 1 << r))
-  else:
-    line('  const bool st_ragged = __builtin_amdgcn_ballot_w64(!st_full && (%s)) != 0;'
-         % ' || '.join('st_col%d' % c for c in range(C)))
+  # no branch inside a step: raggedness is a template parameter, the lane's part of
+  # the store predicate a loop-invariant offset, the row's and the plane's part the
+  # record count of the row's buffer resource (scalar selects)
+  line('  const bool st_ragged = RAGGED;')
+  line('  const unsigned st_voff = st_full ? lane_byte : 0xfffffff0u;')
+  for c in range(C):
+    line('  const unsigned st_voff%d = st_col%d ? lane_byte + %d : 0xfffffff0u;'
+         % (c, c, c * elem))
+  line('  unsigned st_rows = 0;')
+  for r in range(R):
+    line('  if (y_band + %d >= st_ylo && y_band + %d < st_yhi) st_rows |= %du;'
+         % (r, r, 1 << r))
   if mask_loads and ring:
     line('  const i64 ld_rows = a.box_hi[1] + %d < H ? a.box_hi[1] + %d : H;' % (hi[1], hi[1]))
     line('  const i64 ld_plane_bytes = ld_rows * W * %d;' % elem)
@@ -457,24 +414,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('  i64 head = z0 - %d;' % lo[2])
   line('  const i64 steps = (z1 - z0) + %d;' % (L + lo[2]))
   line('  const i64 span = z1 - z0;')
-
-  def active(inst, u):
-    """Condition (wave-uniform) under which `inst` has to run at unrolled step u:
-    its plane head + u - lag - ready... lies inside [z0 - need_lo, z1 + need_hi)."""
-    if not skip_fill or ring or inst.need_lo is None:
-      return None
-    if skip_fill == 2 and inst.stage is not None:     # loads only
-      return None
-    if skip_fill == 3:      # loads only, without a branch (out-of-range offsets)
-      return None
-    # the plane handled at step s = n + u is z0 - lo[2] + s - lag
-    first = lo[2] + inst.lag - inst.need_lo
-    last = lo[2] + inst.lag + inst.need_hi          # s < span + last
-    parts = []
-    if first > 0:
-      parts.append('n + %d >= %d' % (u, first))
-    parts.append('n + %d < span + %d' % (u, last))
-    return ' && '.join(parts)
 
   # `nt`: the non-temporal bit (aux bit 1) on the output stores (2) / the input loads
   # (1); 4 = on the stores of launches whose box does not fit the Infinity Cache (an
@@ -527,7 +466,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     line('  unsigned long long soda_prev = __builtin_readcyclecounter();')
 
   def stamp(k):
-    if fence and not stamps:
+    if not stamps:
       # scheduling fence between the parts of a step: the input plane, each stage
       # instance, the barrier (what the stamped diagnostic build has as well)
       line('      __builtin_amdgcn_sched_barrier(0);')
@@ -615,9 +554,9 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   for u in range(period):
     line('    {  // unrolled step %d' % u)
     edges_done = set()
-    if edge_ahead and not ring:
+    if not ring:      # the first level's rows, ahead of the input plane's part
       ahead = [i for i in insts if i.stage is not None]
-      for inst in (ahead if edge_ahead == 2 else ahead[:1]):
+      for inst in ahead[:1]:
         edges_done.add(id(inst))
         for text in edge_read_lines(inst, u):
           line(text)
@@ -629,12 +568,10 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
         # plane head+u was issued `ring` steps ago; since then this wavefront has
         # issued ring-1 planes of loads and `ring` steps of (at least) R stores
         wait = (ring - 1) * ring_loads + ring * R
-        if flat_stores == 2:     # the ragged instantiation stores column by column
-          ragged_wait = (ring - 1) * ring_loads + ring * R * C
-          line('      __builtin_amdgcn_s_waitcnt(RAGGED ? %d : %d);  // vmcnt(%d / %d)' % (
-              vmcnt(min(63, ragged_wait)), vmcnt(wait), min(63, ragged_wait), wait))
-        else:
-          line('      __builtin_amdgcn_s_waitcnt(%d);  // vmcnt(%d)' % (vmcnt(wait), wait))
+        # (the ragged instantiation stores column by column)
+        ragged_wait = (ring - 1) * ring_loads + ring * R * C
+        line('      __builtin_amdgcn_s_waitcnt(RAGGED ? %d : %d);  // vmcnt(%d / %d)' % (
+            vmcnt(min(63, ragged_wait)), vmcnt(wait), min(63, ragged_wait), wait))
         line('      { %s t[%d][%d];' % (T, R, C))
         line('        soda_ring_read_%s(&in_ring[%d][wave][0][lane * %d], %s);' % (
             name, u % ring, C, ', '.join('t[%d][%d]' % (r, c)
@@ -649,21 +586,13 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
         continue
       if inst.stage is None:
         s = slot(inst, u, 0)
-        cond = active(inst, u)
-        oob = skip_fill == 3 and not ring
-        if oob:      # no branch: planes nobody needs are "loaded" out of range
-          cond = None
-          line('      const unsigned ld_byte_%d = n + %d < span + %d ? ld_lane_byte : '
-               '0xfffffff0u;' % (u, u, lo[2] + inst.lag + inst.need_hi))
-        line('      %s{ i64 zz = head + %d; if (zz > D - 1) zz = D - 1;' % (
-            'if (%s) ' % cond if cond else '', u))
+        line('      { i64 zz = head + %d; if (zz > D - 1) zz = D - 1;' % u)
         line('        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
              'rsrc((void*)(g_in + zz * plane), 0, (int)ld_plane_bytes, 0x27000);')
         for r in range(R):
           line('        { const %s v = __builtin_bit_cast(%s, __builtin_amdgcn_raw_'
                'buffer_load_%s(rs, %s, (unsigned)(%d * W * %d), %d));%s }' % (
-                   vec, vec, suffix, 'ld_byte_%d' % u if oob else 'ld_lane_byte', r, elem,
-                   ld_aux,
+                   vec, vec, suffix, 'ld_lane_byte', r, elem, ld_aux,
                    ''.join(
                        ' %s = v[%d];' % (cell(inst.ident, s, r, c), c)
                        for c in range(C))))
@@ -674,14 +603,13 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
       stage = inst.stage
       ctype = builtin_type(inst.c_type)
       by_name = {(n, rel): src for src, rel, n in inst.reads}
-      cond = active(inst, u)
-      if edge_ahead == 1 and not ring:      # the next level's rows, ahead of this one's
+      if not ring:      # the next level's rows, ahead of this one's
         later = [i for i in insts[insts.index(inst) + 1:] if i.stage is not None]
         if later:                           # (step scope: the next block uses them)
           edges_done.add(id(later[0]))
           for text in edge_read_lines(later[0], u):
             line(text)
-      line('      %s{' % ('if (%s) ' % cond if cond else ''))
+      line('      {')
       if id(inst) not in edges_done:
         for text in edge_read_lines(inst, u):
           line(text)
@@ -689,25 +617,16 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
         ctype = 'pk2'
       if inst.final:
         line('        %s out_tile[%d][%d];' % (ctype, RP, C))
-      by_hand = asm_sched and not pairs and packable(spec) and \
-          kernel_asm.supported(stage)
-      cells = []
       for r in range(RP):
         for c in range(C):
           def load(tensor, rel, u=u, r=r, c=c, inst=inst, by_name=by_name):
             return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, r, c)
           target = ('out_tile[%d][%d]' % (r, c)) if inst.final else \
               '%s[%d][%d][%d]' % (inst.ident, slot(inst, u, 0), r, c)
-          if by_hand:
-            cells.append((target, load))
-          else:
-            cell_assignment(stage, target, load, line, '        ')
-      if by_hand:
-        kernel_asm.emit_cells(stage, cells, line, '        ', group=asm_group,
-                              prefix='a%d_%d' % (u, insts.index(inst)))
+          cell_assignment(stage, target, load, line, '        ')
       if inst.up or inst.down:
         publish(inst, u, slot(inst, u, 0))
-      if inst.final and flat_stores == 2:
+      if inst.final:
         line('        const i64 z = head + %d;' % (u - L))
         line('        const bool z_ok = z >= z0 && z < z1;')
         line('        const unsigned rows_now = z_ok ? st_rows : 0u;')
@@ -725,50 +644,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
               '(unsigned)(%d * W * %d), %s);' % (name, out_cell(r, c), c, r, elem, st_aux)
               for c in range(C)))
           line('        }')
-      elif inst.final and (ring or flat_stores):
-        # the same number of stores every step (the counted wait above): a plane
-        # or row that is not to be stored gets out-of-range offsets
-        line('        const i64 z = head + %d;' % (u - L))
-        line('        const bool z_ok = z >= z0 && z < z1;')
-        line('        {')
-        line('          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
-             'rsrc((void*)(g_out + (z_ok ? z : z0) * plane), 0, (int)plane_bytes, '
-             '0x27000);')
-        for r in range(R):
-          line('          { const bool row_ok = z_ok && y_band + %d >= st_ylo && '
-               'y_band + %d < st_yhi;' % (r, r))
-          line('            if (!st_ragged) { %s v;%s __builtin_amdgcn_raw_buffer_store_%s('
-               '__builtin_bit_cast(%s, v), rs, row_ok && st_full ? lane_byte : '
-               '0xfffffff0u, (unsigned)(%d * W * %d), 0); }' % (
-                   vec, ''.join(' v[%d] = %s;' % (c, out_cell(r, c))
-                                for c in range(C)), suffix, buf_type, r, elem))
-          line('            else {%s }' % ''.join(
-              ' __builtin_amdgcn_raw_buffer_store_b32(%s_bits('
-              '%s), rs, row_ok && st_col%d ? lane_byte + %d : 0xfffffff0u, '
-              '(unsigned)(%d * W * %d), 0);' % (name, out_cell(r, c), c, c * elem, r, elem)
-              for c in range(C)))
-          line('          }')
-        line('        }')
-      elif inst.final:
-        line('        const i64 z = head + %d;' % (u - L))
-        line('        if (z >= z0 && z < z1) {')
-        line('          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
-             'rsrc((void*)(g_out + z * plane), 0, (int)plane_bytes, 0x27000);')
-        for r in range(R):
-          # the row predicate is wave-uniform: a scalar branch
-          line('          if (y_band + %d >= st_ylo && y_band + %d < st_yhi) {' % (r, r))
-          line('            if (!st_ragged) { %s v;%s __builtin_amdgcn_raw_buffer_store_%s('
-               '__builtin_bit_cast(%s, v), rs, st_full ? lane_byte : 0xfffffff0u, '
-               '(unsigned)(%d * W * %d), 0); }' % (
-                   vec, ''.join(' v[%d] = %s;' % (c, out_cell(r, c))
-                                for c in range(C)), suffix, buf_type, r, elem))
-          line('            else {%s }' % ''.join(
-              ' __builtin_amdgcn_raw_buffer_store_b32(%s_bits('
-              '%s), rs, st_col%d ? lane_byte + %d : 0xfffffff0u, '
-              '(unsigned)(%d * W * %d), 0);' % (name, out_cell(r, c), c, c * elem, r, elem)
-              for c in range(C)))
-          line('          }')
-        line('        }')
       line('      }')
     stamp(len(insts) - 1)
     line('    }')
@@ -785,11 +660,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     line('  }')
   line('}')
   line('')
-  occupancy = ''
-  if waves_per_eu > 0:
-    occupancy = ' __attribute__((amdgpu_waves_per_eu(%d, %d)))' % (waves_per_eu,
-                                                                   waves_per_eu)
-  line('GLOBAL WG_SIZE(%d)%s void %s(soda_hip_args a) {' % (G * LANES, occupancy, name))
+  line('GLOBAL WG_SIZE(%d) void %s(soda_hip_args a) {' % (G * LANES, name))
   line('  __attribute__((shared)) %s edges[%d][%d][%d][%d][%d];' % (
       T, max(1, len(publishers)), slots, G + 2, edge_rows, LANES * C))
   if ring:
@@ -798,23 +669,19 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('  const int lane = lane_id();')
   line('  const int wave = __builtin_amdgcn_readfirstlane('
        '__builtin_amdgcn_workitem_id_x() >> 6);')
-  if xcd_tiles:   # see kernel_stream3d_wp: super-tiles dealt to the XCDs
-    line('  const unsigned L = __builtin_amdgcn_workgroup_id_x();')
-    line('  const unsigned SX = (unsigned)a.param[1] & 0xffffu, '
-         'SY = (unsigned)a.param[1] >> 16;')
-    line('  const unsigned nsx = (unsigned)a.param[2] & 0xffffu, '
-         'nsy = (unsigned)a.param[2] >> 16;')
-    # param[3] = P > 0: runs - XCD x = L mod 8 takes tiles [x P, (x + 1) P)
-    line('  const unsigned P = (unsigned)a.param[3];')
-    line('  const unsigned S = SX * SY, i = L >> 3, g = P ? (L & 7u) * P + i : '
-         '(i / S) * 8u + (L & 7u), within = P ? 0u : i % S;')
-    line('  const unsigned block_x = (g % nsx) * SX + within % SX;')
-    line('  const unsigned block_y = ((g / nsx) % nsy) * SY + within / SX;')
-    line('  const unsigned block_z = g / (nsx * nsy);')
-  else:
-    line('  const unsigned block_x = __builtin_amdgcn_workgroup_id_x();')
-    line('  const unsigned block_y = __builtin_amdgcn_workgroup_id_y();')
-    line('  const unsigned block_z = __builtin_amdgcn_workgroup_id_z();')
+  # (a 1-D grid: the kernel places its tiles itself, XCD by XCD)
+  line('  const unsigned L = __builtin_amdgcn_workgroup_id_x();')
+  line('  const unsigned SX = (unsigned)a.param[1] & 0xffffu, '
+       'SY = (unsigned)a.param[1] >> 16;')
+  line('  const unsigned nsx = (unsigned)a.param[2] & 0xffffu, '
+       'nsy = (unsigned)a.param[2] >> 16;')
+  # param[3] = P > 0: runs - XCD x = L mod 8 takes tiles [x P, (x + 1) P)
+  line('  const unsigned P = (unsigned)a.param[3];')
+  line('  const unsigned S = SX * SY, i = L >> 3, g = P ? (L & 7u) * P + i : '
+       '(i / S) * 8u + (L & 7u), within = P ? 0u : i % S;')
+  line('  const unsigned block_x = (g % nsx) * SX + within % SX;')
+  line('  const unsigned block_y = ((g / nsx) % nsy) * SY + within / SX;')
+  line('  const unsigned block_z = g / (nsx * nsy);')
   line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % align_out)
   line('  const i64 xs = x_origin + (i64)block_x * %d;' % w_out)
   line('  if (xs >= a.box_hi[0]) return;')
@@ -831,61 +698,44 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('  i64 wy = yb;')
   line('  if (wy + %d > a.dims[1]) wy = a.dims[1] - %d;' % (TR, TR))
   line('  if (wy < 0) wy = 0;')
-  if skip_bands:
-    # a band whose rows lie outside every stored cell's dependency cone (ragged tiles at
-    # the box's y edges) has nothing to do: its wavefront leaves - the hardware takes
-    # ended wavefronts out of the barrier count - and the SIMD is its partner's alone.
-    # What it would have published is read only by cells outside the cone as well.
-    line('  if (wy + wave * %d >= a.box_hi[1] + %d || wy + (wave + 1) * %d <= a.box_lo[1] - %d) '
-         'return;' % (R, hi[1], R, lo[1]))
-  if flat_stores == 2:
-    # does any lane of this tile store only some of its columns?  (tiles at the box's
-    # x edges when the box does not start or end on a lane boundary)
-    line('  const i64 x = wx + lane * %d;' % C)
-    if nt_auto or wide_stores == 2:
-      line('  const bool streaming = %s;' % stream_expr)
-      line('  const bool ST_WIDE = streaming; (void)ST_WIDE;')
-    for text in store_range:
-      line(text)
-    line('  const bool partial = !(x >= st_lo && x + %d <= st_hi) && (%s);' % (
-        C, ' || '.join('(x + %d >= st_lo && x + %d < st_hi)' % (c, c) for c in range(C))))
-    call = '%s_band<%%s>(a, xs, yb, wx, wy, z0, z1, wave, lane, edges, %s);' % (
-        name, 'in_ring' if ring else 'nullptr')
-    if nt_auto:
-      # a box (input + output) beyond the Infinity Cache: its stores bypass the caches
-      # (kernel_common.NT_STREAMING_BYTES; jacobi3d per launch inside a 512^3 array,
-      # always / never: box 496 222 vs 246 us, 448 161 vs 176, 400 141 vs 153, 344 106
-      # vs 111, 320 85 vs 81, 224 46 vs 40, 112 35 vs 35)
-      line('  const bool ragged = __builtin_amdgcn_ballot_w64(partial) != 0;')
-      line('  if (streaming) { if (ragged) %s else %s }' % (call % 'true, true',
-                                                           call % 'false, true'))
-      line('  else { if (ragged) %s else %s }' % (call % 'true, false',
-                                                  call % 'false, false'))
-    else:
-      line('  if (__builtin_amdgcn_ballot_w64(partial) != 0)')
-      line('    ' + call % 'true')
-      line('  else')
-      line('    ' + call % 'false')
+  # does any lane of this tile store only some of its columns?  (tiles at the box's
+  # x edges when the box does not start or end on a lane boundary)
+  line('  const i64 x = wx + lane * %d;' % C)
+  if nt_auto or wide_stores == 2:
+    line('  const bool streaming = %s;' % stream_expr)
+    line('  const bool ST_WIDE = streaming; (void)ST_WIDE;')
+  for text in store_range:
+    line(text)
+  line('  const bool partial = !(x >= st_lo && x + %d <= st_hi) && (%s);' % (
+      C, ' || '.join('(x + %d >= st_lo && x + %d < st_hi)' % (c, c) for c in range(C))))
+  call = '%s_band<%%s>(a, xs, yb, wx, wy, z0, z1, wave, lane, edges, %s);' % (
+      name, 'in_ring' if ring else 'nullptr')
+  if nt_auto:
+    # a box (input + output) beyond the Infinity Cache: its stores bypass the caches
+    # (kernel_common.NT_STREAMING_BYTES; jacobi3d per launch inside a 512^3 array,
+    # always / never: box 496 222 vs 246 us, 448 161 vs 176, 400 141 vs 153, 344 106
+    # vs 111, 320 85 vs 81, 224 46 vs 40, 112 35 vs 35)
+    line('  const bool ragged = __builtin_amdgcn_ballot_w64(partial) != 0;')
+    line('  if (streaming) { if (ragged) %s else %s }' % (call % 'true, true',
+                                                         call % 'false, true'))
+    line('  else { if (ragged) %s else %s }' % (call % 'true, false',
+                                                call % 'false, false'))
   else:
-    line('  %s_band(a, xs, yb, wx, wy, z0, z1, wave, lane, edges, %s);'
-         % (name, 'in_ring' if ring else 'nullptr'))
+    line('  if (__builtin_amdgcn_ballot_w64(partial) != 0)')
+    line('    ' + call % 'true')
+    line('  else')
+    line('    ' + call % 'false')
   line('}')
   entry = dict(name=name, kind='fused', depth=depth, stage=-1,
                block=[G * LANES, 1, 1], tile=[w_out, r_out, chunk_planes, 1],
                origin_align=align_out, fill_rows=L + lo[2], cols=C, rows=R, stack=G,
                prefetch=prefetch, period=period, est_vgprs=est_vgprs, w_out=w_out,
                r_out=r_out, lds_bytes=lds_bytes + ring_bytes, ring=ring, pairs=pairs,
-               xcd_tiles=(-1 if xcd_runs else 1) if xcd_tiles else 0,
-               skip_fill=int(bool(skip_fill and not ring)), fence=int(bool(fence)),
-               asm_sched=int(bool(asm_sched and not pairs)),
-               flat_stores=int(flat_stores),
-               min_extent=[LANES * C, TR])
+               xcd_tiles=-1, min_extent=[LANES * C, TR])
   if nt:                    # (only when set: the shipped kernels' calibration keys stay)
     entry['nt'] = int(nt)
   if mask_loads:
     entry['mask_loads'] = 1
-  if skip_bands:
-    entry['skip_bands'] = 1
   if wide_stores:
     entry['wide_stores'] = int(wide_stores)
   return '\n'.join(o) + '\n', entry

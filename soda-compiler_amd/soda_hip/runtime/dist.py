@@ -307,6 +307,7 @@ class StreamSchedule:
   after that stream's earlier work, and req.wait() makes the side stream (not
   the host) wait for it."""
   overlapped = True
+  skip_exchange = False      # see SerialSchedule
 
   def __init__(self, torch, host_sync=False):
     """host_sync: the backend reads device memory from the host side without

@@ -190,6 +190,9 @@ def kernel_descs(table):
     d.step_ns_one = int(k.get('step_ns_one', 0))
     d.stream_gbps = int(k.get('stream_gbps', 0))
     d.xcd_tiles = int(k.get('xcd_tiles', 0))
+    d.stream_wgs_per_cu = int(k.get('stream_wgs_per_cu', 0))
+    d.fade_lo_mib = int(k.get('fade_lo_mib', 0))
+    d.fade_hi_mib = int(k.get('fade_hi_mib', 0))
   return arr
 
 

@@ -47,12 +47,30 @@ def test_abi_version_and_error_names(lib):
   assert lib.soda_hip_error_name(0) == b'ok'
 
 
-def test_struct_layouts_match_the_header(lib):
+def test_struct_layouts_match_the_header(lib, tmp_path):
   # soda_hip_args is what the generated kernels receive by value
   assert ctypes.sizeof(capi.BufferT) == 72          # legacy Halide buffer_t
-  assert ctypes.sizeof(capi.KernelDesc) == 96 + 4 * (3 + 3 + 4 + 1 + 3 + 2 + 3 + 1)
+  assert ctypes.sizeof(capi.KernelDesc) == 96 + 4 * (3 + 3 + 4 + 1 + 3 + 2 + 3 + 1 + 3)
   assert ctypes.sizeof(capi.Window) == 4 * (2 + 4 + 4)
   assert ctypes.sizeof(capi.ProgramDesc) == 4 * (4 + 16 + 8 + 1) + 64 * 40
+  # ... and against the C compiler's view of include/soda_hip.h: size of every struct
+  # the binding mirrors and the offset of every field of the kernel descriptor
+  import subprocess
+  fields = [name for name, _ in capi.KernelDesc._fields_]
+  src = tmp_path / 'layout.c'
+  src.write_text(
+      '#include <stdio.h>\n#include <stddef.h>\n#include "soda_hip.h"\n'
+      'int main(void) {\n'
+      '  printf("%zu %zu %zu %zu %zu\\n", sizeof(soda_hip_kernel), sizeof(soda_hip_window),\n'
+      '         sizeof(soda_hip_program), sizeof(soda_hip_slab), sizeof(soda_hip_timing));\n' +
+      ''.join('  printf("%%zu\\n", offsetof(soda_hip_kernel, %s));\n' % f for f in fields) +
+      '  return 0;\n}\n')
+  exe = tmp_path / 'layout'
+  subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+  out = subprocess.check_output([str(exe)], text=True).split()
+  assert [int(v) for v in out[:5]] == [ctypes.sizeof(t) for t in (
+      capi.KernelDesc, capi.Window, capi.ProgramDesc, capi.Slab, capi.Timing)]
+  assert [int(v) for v in out[5:]] == [getattr(capi.KernelDesc, f).offset for f in fields]
 
 
 def test_null_arguments_are_errors_not_crashes(lib):

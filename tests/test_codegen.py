@@ -113,9 +113,8 @@ def test_every_sample_compiles_for_gfx950(app, tmp_path):
 
 @pytest.mark.parametrize('options', [
     dict(wave_groups=4), dict(wave_groups=4, pairs=1, vgpr_budget=250),
-    dict(wave_groups=4, pairs=1, vgpr_budget=250, dppadd=1, sync=3),
     dict(wave_groups=4, pairs=2, vgpr_budget=250, ring=6),
-    dict(wave_groups=4, pairs=2, vgpr_budget=250, ring=12, max_period=12, sync=2)])
+    dict(wave_groups=4, pairs=2, vgpr_budget=250, ring=12, max_period=12)])
 def test_wave_pipelined_forms_compile(options, tmp_path):
   """The experimental wave-pipelined form of the fused 2-D kernel (one wavefront
   per group of levels, LDS hand-off) and its packed-pair variant build for
@@ -131,11 +130,11 @@ def test_wave_pipelined_forms_compile(options, tmp_path):
   if options.get('pairs') == 2:     # one strip of twice the width
     assert fused[0]['tile'][0] == fused[0]['w_out'] == 512 - 16
     assert fused[0]['min_extent'] == [512, 1] and 'pk_wide_below(' in text
-  if options.get('dppadd'):
+  if options.get('pairs') == 1:     # lane-crossing operands as two scalar DPP adds
     assert 'pk_from_lane_below(' in text
-  assert fused[0].get('sync', 1) == options.get('sync', 1)
-  if options.get('sync', 1) > 1:
-    assert fused[0]['period'] % (2 * options['sync']) == 0
+  # options that were measured null twice are gone: asking for one is an error
+  with pytest.raises(TypeError):
+    kernel.generate(spec, depths=[8], wave_groups=4, sync=3)
   out = tmp_path / 'wp.hsaco'
   kernel.compile_to_code_object(text, str(out))
   assert open(out, 'rb').read(4) == b'\x7fELF'
@@ -160,11 +159,13 @@ def test_default_depth_sets():
   assert sorted(fused) == [1, 2, 4, 8, 12, 16, 20, 24]
   assert all(k['step_valu'] > 0 and k['step_bytes'] > 0 for k in fused.values())
   assert fused[24]['tile'][0] == 464 and fused[20]['tile'][0] == 472
-  # (strips on 64-byte pieces are an option: measured, slower under sustained load)
+  # (strips on 64-byte pieces were measured: slower under sustained load; gone)
   assert fused[24]['origin_align'] == 4 and fused[2]['origin_align'] == 32
-  pieces = {k['depth']: k for k in kernel.generate(spec_of('jacobi2d', iterate=1000),
-                                                   align='store64')[1] if k['kind'] == 'fused'}
-  assert pieces[20]['tile'][0] == 464 and pieces[20]['origin_align'] == 16
+  # depth 1: seam-free strips (no stage is read across lanes), six rows in flight, at
+  # most two workgroups per CU on arrays beyond the caches
+  assert fused[1]['exact'] == 1 and fused[1]['halo'] == [0, 0] and fused[1]['tile'][0] == 1024
+  assert fused[1]['prefetch'] == 6 and fused[1]['stream_wgs_per_cu'] == 2
+  assert not fused[2].get('exact') and not fused[2].get('stream_wgs_per_cu')
   assert fused[24]['fill_rows'] == 51
   assert fused[12]['groups'] == 4 and fused[12]['pairs'] and not fused[8].get('groups')
   k16 = fused[16]
@@ -200,7 +201,7 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   assert blk[0]['origin_align'] == 16
   # input planes through the two-slot LDS ring
   assert blk[0]['min_extent'] == [128, 64]
-  assert (blk[0]['prefetch'], blk[0]['ring'], blk[0]['asm_sched']) == (0, 2, 0)
+  assert (blk[0]['prefetch'], blk[0]['ring']) == (0, 2)
   # launches beyond the Infinity Cache store around the caches: an instantiation of
   # its own, chosen by the kernel's entry from the box it is given
   assert blk[0]['nt'] == 4 and '_band<false, true>(' in text
@@ -212,9 +213,11 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
                   if k.get('stack') and k['depth'] == 4]
   assert (in_registers[0]['prefetch'], in_registers[0]['ring']) == (1, 0)
   assert blk[0]['xcd_tiles'] == -1 and blk[0]['fill_rows'] == 8
-  loose = [k for k in kernel.generate(spec, blk_align_out=2, blk_xcd_runs=0)[1]
-           if k.get('stack') and k['depth'] == 4]
-  assert loose[0]['tile'][:2] == [120, 56] and loose[0]['xcd_tiles'] == 1
+  # options that were measured null twice are gone: asking for one is an error
+  with pytest.raises(TypeError):
+    kernel.generate(spec, blk_skip_fill=1)
+  with pytest.raises(TypeError):
+    kernel.generate(spec, blk_asm_sched=1)
   assert 'edges[' in text and 'soda_lds_barrier' in text
   k4 = [k for k in table if k['kind'] == 'fused' and k['depth'] == 4 and k.get('groups')]
   assert k4 and k4[0]['groups'] == 4 and k4[0]['block'] == [256, 1, 1]
@@ -231,12 +234,11 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   heat = kernel.generate(spec_of('heat3d', iterate=8))[1]
   assert [k.get('pairs') for k in heat if k['depth'] == 4 and k.get('groups')] == [1]
   # heavy plain-float programs: packed pair-rows in the block form too (the ring freed
-  # the registers for them); hand-ordered arithmetic when asked for / pairs refused
-  assert [(k['name'], k['ring'], k['pairs'], k['asm_sched']) for k in heat
-          if k.get('stack') and k['depth'] == 4] == [('heat3d_fused_k4b', 2, 1, 0)]
-  by_hand = kernel.generate(spec_of('heat3d', iterate=8), blk_pairs=0)[1]
-  assert [(k['pairs'], k['asm_sched']) for k in by_hand
-          if k.get('stack') and k['depth'] == 4] == [(0, 1)]
+  # the registers for them)
+  assert [(k['name'], k['ring'], k['pairs']) for k in heat
+          if k.get('stack') and k['depth'] == 4] == [('heat3d_fused_k4b', 2, 1)]
+  scalar = kernel.generate(spec_of('heat3d', iterate=8), blk_pairs=0)[1]
+  assert [k['pairs'] for k in scalar if k.get('stack') and k['depth'] == 4] == [0]
   # the block form serves depths 1 and 2 as well, next to the single-wave kernels
   # (which stay for arrays below its 128 x 64 tile and programs it does not take)
   assert [k['name'] for k in table if k['kind'] == 'fused' and k['depth'] <= 2] == [

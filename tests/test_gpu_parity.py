@@ -143,20 +143,13 @@ EXPERIMENTAL_FORMS = [
     ('seidel2d', dict(wave_groups=4, pairs=1, vgpr_budget=250, ring=6, waves_per_eu=4)),
     ('seidel2d', dict(wave_groups=4, pairs=1, vgpr_budget=250)),
     ('blur', dict(wave_groups=4, vgpr_budget=200)),
-    # scalar DPP adds for the lane-crossing operands of packed pairs
-    ('jacobi2d', dict(wave_groups=4, pairs=1, vgpr_budget=250, ring=6, dppadd=1)),
     ('seidel2d', dict(wave_groups=4, pairs=2, vgpr_budget=250, ring=12, max_period=12)),
-    # one barrier per 3 (2) streamed rows
-    ('jacobi2d', dict(wave_groups=4, pairs=2, vgpr_budget=250, ring=6, sync=3)),
-    ('jacobi2d', dict(wave_groups=4, vgpr_budget=250, sync=3)),
-    ('seidel2d', dict(wave_groups=2, pairs=2, vgpr_budget=250, ring=12, max_period=12,
-                      sync=2)),
-    ('blur', dict(wave_groups=4, vgpr_budget=200, sync=3))]
+    ('seidel2d', dict(wave_groups=2, pairs=2, vgpr_budget=250, ring=12, max_period=12))]
 
 
-# (scalar pipelined; packed pairs with scalar DPP adds: the two code paths of the
+# (scalar pipelined; two packed strips with scalar DPP adds: the two code paths of the
 # generator that no shipped form goes through)
-ALWAYS_TESTED_EXPERIMENTAL = (0, 8)
+ALWAYS_TESTED_EXPERIMENTAL = (0, 3)
 
 
 def _tested_forms():
@@ -278,18 +271,21 @@ def test_3d_wave_pipelined_forms_on_heat3d(options):
   forms: packed pair-rows (the default for float programs) and scalar,
   LDS-direct loader wavefront, one row block per wavefront, register prefetch."""
   from soda_hip.codegen import kernel
-  for shape, iterate in (((30, 45, 70), 4), ((24, 64, 131), 9)):
-    spec = gpu_util.load_spec('heat3d', iterate=iterate)
-    text, table = kernel.generate(spec, depths=[2, 4], **options)
-    assert any(k['depth'] == 4 for k in table)
-    prog = host.open_program(source=text, spec=spec)
-    inputs = gpu_util.random_inputs(spec, shape)
-    got, timing = prog.run_numpy(inputs, iterate=iterate, timed=True)
-    assert timing['max_depth'] == 4
-    orc = gpu_util.make_oracle(spec)
-    want = orc.run(inputs, iterate=iterate)[spec['outputs'][0]]
-    sl = orc.valid_slices(tuple(reversed(shape)), iterate)
-    assert np.array_equal(got[0][sl], want[sl], equal_nan=True), (options, shape)
+  # (one code object per form: a blob serves any run-time iteration count)
+  spec = gpu_util.load_spec('heat3d', iterate=9)
+  text, table = kernel.generate(spec, depths=[2, 4], **options)
+  assert any(k['depth'] == 4 for k in table)
+  prog = host.open_program(source=text, spec=spec)
+  orc = gpu_util.make_oracle(spec)
+  try:
+    for shape, iterate in (((30, 45, 70), 4), ((24, 64, 131), 9)):
+      inputs = gpu_util.random_inputs(spec, shape)
+      got, timing = prog.run_numpy(inputs, iterate=iterate, timed=True)
+      assert timing['max_depth'] == 4
+      want = orc.run(inputs, iterate=iterate)[spec['outputs'][0]]
+      sl = orc.valid_slices(tuple(reversed(shape)), iterate)
+      assert np.array_equal(got[0][sl], want[sl], equal_nan=True), (options, shape)
+  finally:
     prog.close()
     prog.blob.unload()
 
@@ -298,57 +294,42 @@ def test_3d_wave_pipelined_forms_on_heat3d(options):
     ('jacobi3d', dict(deep3d='blk')),                      # 8 bands, LDS ring of 2 planes
     ('jacobi3d', dict(deep3d='blk', blk_prefetch=1)),      # ... one plane ahead in registers
     ('heat3d', dict(deep3d='blk')),                        # ring + packed pair-rows
-    ('heat3d', dict(deep3d='blk', blk_pairs=0)),           # ring + hand-ordered arithmetic
+    ('heat3d', dict(deep3d='blk', blk_pairs=0)),           # ring, scalar arithmetic
     ('jacobi3d', dict(deep3d='blk', blk_mask_loads=0)),    # unmasked global_load_lds ring
-    ('jacobi3d', dict(deep3d='blk', blk_skip_bands=1)),    # idle bands of ragged tiles leave
     # row segments stored in whole 64-byte pieces (shipped: only in launches beyond the
     # Infinity Cache - the full-size tests; forced on here), and never
     ('jacobi3d', dict(deep3d='blk', blk_wide_stores=1)),
     ('heat3d', dict(deep3d='blk', blk_wide_stores=1, blk_nt=2)),
     ('jacobi3d', dict(deep3d='blk', blk_wide_stores=0)),
-    ('jacobi3d', dict(deep3d='blk', blk_prefetch=1, blk_mask_loads=0)),
     ('jacobi3d', dict(deep3d='blk', blk_stack=4, blk_prefetch=0)),
-    ('jacobi3d', dict(deep3d='blk', blk_stack=8, blk_rows=4, blk_prefetch=2)),
-    # packed pair-rows; input planes through per-wavefront LDS rings (counted waits)
+    # packed pair-rows for a light program; four bands per workgroup
     ('jacobi3d', dict(deep3d='blk', blk_pairs=1)),
-    ('jacobi3d', dict(deep3d='blk', blk_prefetch=0, blk_ring=2)),
-    ('heat3d', dict(deep3d='blk', blk_stack=4, blk_prefetch=0, blk_pairs=1, blk_ring=2)),
-    ('heat3d', dict(deep3d='blk', blk_stack=4)),
-    # round 3: the shipped form has no branch inside a step (flat_stores=2), scheduling
-    # fences and the next level's edge rows read ahead; the older store paths, the
-    # hand-ordered arithmetic (kernel_asm), the fill-skipping variants and unaligned
-    # tiles in plain order stay correct
-    ('jacobi3d', dict(deep3d='blk', blk_prefetch=1, blk_flat_stores=0, blk_fence=0,
-                      blk_edge_ahead=0)),
-    ('jacobi3d', dict(deep3d='blk', blk_prefetch=1, blk_flat_stores=1, blk_edge_ahead=2)),
-    ('jacobi3d', dict(deep3d='blk', blk_asm_sched=1)),
-    ('heat3d', dict(deep3d='blk', blk_prefetch=1, blk_asm_sched=1, blk_asm_group=8)),
-    ('jacobi3d', dict(deep3d='blk', blk_prefetch=1, blk_skip_fill=1, blk_flat_stores=0)),
-    ('heat3d', dict(deep3d='blk', blk_prefetch=1, blk_skip_fill=3)),
-    ('jacobi3d', dict(deep3d='blk', blk_align_out=2, blk_xcd_runs=0)),
-    ('jacobi3d', dict(deep3d='blk', blk_align_out=32))])
+    ('heat3d', dict(deep3d='blk', blk_stack=4, blk_prefetch=0, blk_pairs=1, blk_ring=2))])
 def test_3d_block_form(app, options):
   """The block form of the depth-4 3-D kernel (kernel_stream3d_blk: all levels in
   every wavefront, bands of rows per wavefront, edge rows through LDS, tiles
   moved inside the array, raw-buffer loads and stores) ALONE - no wave-pipelined
   kernel next to it - on ragged shapes at and above its smallest array."""
   from soda_hip.codegen import kernel
-  for shape, iterate in (((30, 64, 128), 4), ((45, 131, 140), 9), ((150, 70, 257), 13)):
-    spec = gpu_util.load_spec(app, iterate=iterate)
-    text, table = kernel.generate(spec, depths=[2, 4], **options)
-    deep = [k for k in table if k['depth'] == 4]
-    assert [bool(k.get('stack')) for k in deep] == [True], [k['name'] for k in deep]
-    if shape[1] < deep[0]['min_extent'][1] or shape[2] < deep[0]['min_extent'][0]:
-      continue
-    prog = host.open_program(source=text, spec=spec)
-    inputs = gpu_util.random_inputs(spec, shape)
-    got, timing = prog.run_numpy(inputs, iterate=iterate, timed=True)
-    assert timing['max_depth'] == 4
-    orc = gpu_util.make_oracle(spec)
-    want = orc.run(inputs, iterate=iterate)[spec['outputs'][0]]
-    sl = orc.valid_slices(tuple(reversed(shape)), iterate)
-    assert want[sl].size > 0
-    assert np.array_equal(got[0][sl], want[sl], equal_nan=True), (options, shape)
+  # (one code object per form: a blob serves any run-time iteration count)
+  spec = gpu_util.load_spec(app, iterate=13)
+  text, table = kernel.generate(spec, depths=[2, 4], **options)
+  deep = [k for k in table if k['depth'] == 4]
+  assert [bool(k.get('stack')) for k in deep] == [True], [k['name'] for k in deep]
+  prog = host.open_program(source=text, spec=spec)
+  orc = gpu_util.make_oracle(spec)
+  try:
+    for shape, iterate in (((30, 64, 128), 4), ((45, 131, 140), 9), ((150, 70, 257), 13)):
+      if shape[1] < deep[0]['min_extent'][1] or shape[2] < deep[0]['min_extent'][0]:
+        continue
+      inputs = gpu_util.random_inputs(spec, shape)
+      got, timing = prog.run_numpy(inputs, iterate=iterate, timed=True)
+      assert timing['max_depth'] == 4
+      want = orc.run(inputs, iterate=iterate)[spec['outputs'][0]]
+      sl = orc.valid_slices(tuple(reversed(shape)), iterate)
+      assert want[sl].size > 0
+      assert np.array_equal(got[0][sl], want[sl], equal_nan=True), (options, shape)
+  finally:
     prog.close()
     prog.blob.unload()
 

@@ -62,3 +62,43 @@ def test_split_argument_reads_back_a_depth_schedule():
   for bad, iterate in (('41x24', 1000), ('24', 24), ('ax4', 4), ('0x4+1x4', 4), ('1x4+', 4)):
     with pytest.raises(SystemExit):
       bench.parse_split(bad, iterate)
+
+
+def _round_of(path):
+  import re
+  return int(re.match(r'r(\d+)_', os.path.basename(path)).group(1))
+
+
+def test_profiles_are_stamped_with_a_clean_commit():
+  """From round 4 on every entry of the traffic and SQ-counter files names the commit the
+  GPU box ran (tools/collect.sh refuses a dirty tree and stamps the snapshot): no
+  '+uncommitted', no missing stamp."""
+  checked = 0
+  for pattern in ('r*_traffic.json', 'r*_sq_counters.json'):
+    for path in glob.glob(os.path.join(ROOT, 'profiles', pattern)):
+      if _round_of(path) < 4:
+        continue
+      with open(path) as f:
+        for e in json.load(f)['entries']:
+          assert e.get('commit') and not e['commit'].endswith('+uncommitted') and \
+              e['commit'] != 'unknown', (path, e.get('kernel'), e.get('commit'))
+          checked += 1
+  newest = max(_round_of(p) for p in glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
+  assert newest < 4 or checked > 0
+
+
+def test_stats_pass_reproduces_the_bench_line():
+  """From round 4 on the --kernel-trace --stats pass runs the schedule of the plain run
+  (bench.py --split): every kernel is called sweeps x launches-per-sweep times, and the
+  summary's average durations add up to the line's own ms_per_step within 2 %."""
+  for path in glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_under_rocprof.json')):
+    if _round_of(path) < 4:
+      continue
+    with open(path) as f:
+      record = json.load(f)
+    check = record['check']
+    assert record['commit'] and not record['commit'].endswith('+uncommitted')
+    stats = {k['name']: k for k in record['kernel_stats']}
+    for name, calls in check['calls_expected'].items():
+      assert stats[name]['calls'] == calls, (name, stats[name]['calls'], calls)
+    assert abs(check['ratio'] - 1) < 0.02, check

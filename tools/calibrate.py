@@ -11,6 +11,9 @@ that deep kernel:
   * cache-resident array, chip full          -> step_ns_full
   * cache-resident array, <= 1 workgroup/CU   -> step_ns_one  (forced long chunks)
   * array far beyond the Infinity Cache       -> stream_gbps
+  * an array in between (about twice the cache) -> fade_lo_mib / fade_hi_mib: the
+    footprints between which the HBM term of the price fades in (soda_hip.cpp:
+    step_seconds), placed so that the model reproduces this launch
 step = launch time / (rounds x (chunk + fill rows)), from the library's own launch
 trace (SODA_HIP_LAUNCH_TRACE).
 
@@ -22,10 +25,31 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SIZES = {   # (cache-resident, streaming) extents per dimension
-    2: (3072, 16384),
-    3: (256, 512),
+SIZES = {   # (cache-resident, streaming, in between) extents per dimension
+    2: (3072, 16384, 8192),
+    3: (256, 512, 384),
 }
+FADE_DEFAULT = (128, 512)      # MiB; soda_hip.cpp: kCacheResidentMiB, kStreamingMiB
+
+
+def fade_footprints(spec, mid_extent, cached_ns, mid_ns, stream_ns):
+  """(fade_lo_mib, fade_hi_mib) from the step time on the in-between array: weight w of
+  the HBM term there = how far its step has moved from the cache-resident one towards
+  the streaming one; the fade is the line through (fade_lo, 0) and (footprint, w)."""
+  from soda_hip.codegen import spec as specmod
+  types = specmod.tensor_c_types(spec)
+  cell = sum(specmod.ELEM_SIZE[t['c_type']] for t in spec['inputs']) + \
+      sum(specmod.ELEM_SIZE[types[n]] for n in spec['outputs'])
+  footprint = cell * float(mid_extent) ** spec['dim'] / 2.0 ** 20
+  lo, hi = FADE_DEFAULT
+  if stream_ns <= cached_ns * 1.05:      # never bound by HBM: nothing to place
+    return lo, hi
+  w = (mid_ns - cached_ns) / (stream_ns - cached_ns)
+  if w <= 0.1:        # still cache-speed at this footprint: the fade starts here
+    return int(footprint), int(max(2 * footprint, hi))
+  if w >= 0.95:       # already streaming
+    return int(min(lo, footprint / 2)), int(footprint)
+  return lo, int(min(8192, max(footprint, lo + (footprint - lo) / w)))
 APPS = ['jacobi2d', 'seidel2d', 'blur', 'sobel2d', 'jacobi3d', 'heat3d']
 TRACE = re.compile(r'launch\s+\d+ (\S+)\s+([\d.]+) us \(model\s+[\d.]+\)  box (\d+) x (\d+) x (\d+)  '
                    r'grid (\d+) x (\d+) x (\d+)  chunk (\d+)  fill (\d+)  resident (\d+)')
@@ -118,7 +142,7 @@ def main():
     spec = specmod.spec_from_stencil(st)
     _, kernels = kernel.generate(spec)
     dim = spec['dim']
-    small, big = SIZES[dim]
+    small, big, between = SIZES[dim]
     for k in kernels:
       if k['kind'] != 'fused' or not k.get('fill_rows'):
         continue
@@ -134,21 +158,32 @@ def main():
       long_chunk = min(small, -(-small * inner // 240 // 4) * 4 + 4)
       one = measure(app, k['depth'], form, small, chunk=max(8, long_chunk), name=k['name'])
       stream = measure(app, k['depth'], form, big, name=k['name'])
-      if not one or not stream:
+      mid = measure(app, k['depth'], form, between, name=k['name'])
+      if not one or not stream or not mid:
         print('%-28s partly measured' % k['name'])
         continue
       active = min(stream['blocks'], stream['resident'])
       gbps = active * k['step_bytes'] / stream['step_ns']      # bytes / ns = GB/s
+      # the step on the in-between array, at the occupancy it ran at, against the cached
+      # and the streaming step at that occupancy
+      share = min(1.0, mid['blocks'] / max(1.0, mid['resident']))
+      cached_ns = one['step_ns'] + (full['step_ns'] - one['step_ns']) * share
+      fade_lo, fade_hi = fade_footprints(
+          specmod.inline_pointwise(spec), between, cached_ns, mid['step_ns'],
+          max(cached_ns, min(mid['blocks'], mid['resident']) * k['step_bytes'] / gbps))
       table['kernels'][full['key']] = dict(
           name=k['name'], app=app, step_ns_full=int(round(full['step_ns'])),
           step_ns_one=int(round(one['step_ns'])), stream_gbps=int(round(gbps)),
+          fade_lo_mib=fade_lo, fade_hi_mib=fade_hi,
           measured=dict(full=[small, full['blocks'], full['steps'], full['us']],
                         one=[small, one['blocks'], one['steps'], one['us']],
-                        stream=[big, stream['blocks'], stream['steps'], stream['us']]))
+                        stream=[big, stream['blocks'], stream['steps'], stream['us']],
+                        between=[between, mid['blocks'], mid['steps'], mid['us']]))
       print('%-28s full %6.0f ns/step (%4d wgs)  one %6.0f ns/step (%4d wgs)  stream %5.0f '
-            'GB/s of step_bytes (%4d wgs, %.0f ns/step)' % (
-                k['name'], full['step_ns'], full['blocks'], one['step_ns'], one['blocks'],
-                gbps, stream['blocks'], stream['step_ns']), flush=True)
+            'GB/s of step_bytes (%4d wgs, %.0f ns/step)  at %d: %.0f ns/step -> fade %d..%d MiB'
+            % (k['name'], full['step_ns'], full['blocks'], one['step_ns'], one['blocks'],
+               gbps, stream['blocks'], stream['step_ns'], between, mid['step_ns'], fade_lo,
+               fade_hi), flush=True)
   # entries of the calibrated apps whose kernel shape no longer exists are stale
   live = set()
   for app in apps:

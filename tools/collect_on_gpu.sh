@@ -9,8 +9,18 @@ tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out
 rm -rf $out/prof_$tag $out/pmc_${tag}_*
+# which tree the kernels were built from (written by tools/collect.sh before the call)
+cp tools/.collect_commit $out/pmc_${tag}_commit.txt 2>/dev/null || echo unknown > $out/pmc_${tag}_commit.txt
+# The --stats pass repeats the schedule a PLAIN run settles on (bench.py --split): with
+# the tuning step under the profiler the summary's AverageNs mixed candidate splits into
+# every kernel's average (r03: 574 calls of the depth-24 kernel for 40 per sweep).  With
+# the split given: 1 warm-up + 3 timed + 3 event-bracketed sweeps = 7 x launches_per_step
+# calls, and sum(launches_i x AverageNs_i) is comparable with the line's ms_per_step.
+plain=$(python3 bench.py --steps 10 --warmup 5 --cpu-seconds 0 2>/dev/null | grep "^{" | tail -1)
+echo "$plain" > $out/prof_${tag}_plain_bench.json
+hsplit=$(echo "$plain" | python3 -c "import sys, json; print(json.loads(sys.stdin.read())['config']['depth_schedule'])")
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$tag -- \
-    python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 > $out/prof_${tag}_bench.log 2>&1
+    python3 bench.py --split "$hsplit" --steps 3 --warmup 1 --cpu-seconds 0 > $out/prof_${tag}_bench.log 2>&1
 grep "^{" $out/prof_${tag}_bench.log | cut -c1-300
 # name|bench arguments   (the workload table tools/collect_profiles.py reads back)
 cat > $out/pmc_${tag}_workloads.txt <<'WL'

@@ -86,13 +86,12 @@ def main():
   if stats:
     shutil.copy(max(stats, key=os.path.getmtime),
                 os.path.join(dst, '%s_kernel_stats.csv' % tag))
+  # the tree the GPU box ran: stamped by tools/collect.sh when the call was made (the
+  # snapshot has no .git) - never this checkout's state at post-processing time
   try:
-    commit = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'],
-                                     cwd=ROOT, text=True).strip()
-    if subprocess.check_output(['git', 'status', '--porcelain', '--', 'soda-compiler_amd'],
-                               cwd=ROOT, text=True).strip():
-      commit += '+uncommitted'
-  except (OSError, subprocess.CalledProcessError):
+    with open(os.path.join(src, 'pmc_%s_commit.txt' % tag)) as f:
+      commit = f.read().strip() or None
+  except OSError:
     commit = None
   entries = []
   with open(os.path.join(src, 'pmc_%s_workloads.txt' % tag)) as f:
@@ -183,8 +182,41 @@ def main():
   if os.path.exists(p):
     with open(p) as f:
       lines = [l for l in f if l.startswith('{"metric')]
+    # the bench line of the --stats pass WITH the summary rows of its kernels and the
+    # cross-check the two allow: sum over the sweep's launches of the summary's average
+    # duration of each launch's kernel against the line's own ms_per_step
+    record = dict(bench=json.loads(lines[-1]) if lines else None, commit=commit,
+                  kernel_stats=[], check=None)
+    if stats and lines:
+      app = record['bench']['config']['app']
+      with open(max(stats, key=os.path.getmtime)) as f:
+        rows = {r['Name'].split('(')[0]: r for r in csv.DictReader(f)}
+      for name, r in sorted(rows.items()):
+        if name.startswith(app + '_'):
+          record['kernel_stats'].append(dict(
+              name=name, calls=int(r['Calls']), average_ns=float(r['AverageNs']),
+              total_ns=float(r['TotalDurationNs']), min_ns=float(r['MinNs']),
+              max_ns=float(r['MaxNs'])))
+      total_ns, per_step = 0.0, {}
+      for part in record['bench']['config']['depth_schedule'].split('+'):
+        count, _, depth = part.partition('x')
+        name = '%s_fused_k%s' % (app, depth)
+        mine = [k for k in record['kernel_stats'] if k['name'] == name]
+        if mine:
+          total_ns += int(count) * mine[0]['average_ns']
+          per_step[name] = per_step.get(name, 0) + int(count)
+      sweeps = record['bench']['steps'] + record['bench']['warmup'] + 3
+      record['check'] = dict(
+          launches_per_step=per_step, sweeps_in_the_pass=sweeps,
+          calls_expected={n: c * sweeps for n, c in per_step.items()},
+          sum_of_average_ns_ms=total_ns / 1e6, ms_per_step=record['bench']['ms_per_step'],
+          ratio=total_ns / 1e6 / record['bench']['ms_per_step'])
+      print('--stats cross-check: sum(launches x AverageNs) = %.3f ms, ms_per_step = %.3f '
+            '(ratio %.3f)' % (total_ns / 1e6, record['bench']['ms_per_step'],
+                              record['check']['ratio']))
     with open(os.path.join(dst, '%s_bench_under_rocprof.json' % tag), 'w') as f:
-      f.writelines(lines)
+      json.dump(record, f, indent=1, sort_keys=True)
+      f.write('\n')
   for e in entries:
     print('%-10s %-28s %-18s read %8.1f MB  write %8.1f MB  read/write %.2f  (%d launches)' % (
         e['workload'], e['kernel'], 'x'.join(map(str, e['dims'])),

@@ -107,6 +107,30 @@ __global__ void __launch_bounds__(64 * WPB) copy_rows_lds(const float* __restric
   __builtin_amdgcn_s_waitcnt(0);
 }
 
+// tiles: a wavefront loads R + 2 rows of its 256 columns (all issued at once: nothing is
+// carried from tile to tile), stores R, and ends; workgroups are dispatched x fastest, so
+// the whole chip sweeps down the array together as the one-float4-per-thread copy does -
+// the shape a depth-1 stencil kernel WITHOUT a row pipeline would have (halo rows are
+// re-read by the tile below, on the same XCD: workgroup id mod 8 = strip mod 8)
+template <int R, int WPB, int NT>
+__global__ void __launch_bounds__(64 * WPB) copy_tiles(const float* __restrict__ in, float* __restrict__ out,
+                                                       long W, long H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long x = ((long)blockIdx.x * WPB + wave) * 256 + lane * 4;
+  const long y0 = (long)blockIdx.y * R;
+  f4 r[R + 2];
+#pragma unroll
+  for (int p = 0; p < R + 2; ++p) {
+    long y = y0 - 1 + p; if (y < 0) y = 0; if (y > H - 1) y = H - 1;
+    r[p] = ld<NT>((const f4*)(in + y * W + x));
+  }
+#pragma unroll
+  for (int p = 0; p < R; ++p) {
+    const f4 v = (r[p] + r[p + 1]) + r[p + 2];        // something of all three rows
+    if (y0 + p < H) st<NT>((f4*)(out + (y0 + p) * W + x), v);
+  }
+}
+
 template <int NT>
 __global__ void __launch_bounds__(256) fill_gs(f4* __restrict__ out, size_t n) {
   const size_t T = (size_t)gridDim.x * blockDim.x;
@@ -197,6 +221,23 @@ int main(int argc, char** argv) {
     timeit(name, 2.0 * bytes, [&] { copy_rows_lds<8, 4, 2><<<grid, 256>>>(a, b, W, H, chunk); });
     snprintf(name, sizeof name, "rows via LDS ring of 16, 4 waves/blk, nt stores, chunk %ld", chunk);
     timeit(name, 2.0 * bytes, [&] { copy_rows_lds<16, 4, 2><<<grid, 256>>>(a, b, W, H, chunk); });
+  }
+  printf("== tiles of R rows, R + 2 loaded, no row pipeline (TB/s of the 2 GiB of unique bytes)\n");
+  {
+    dim3 g8((unsigned)(W / 256 / 4), (unsigned)(H / 8)), g16((unsigned)(W / 256 / 4), (unsigned)(H / 16)),
+        g32((unsigned)(W / 256 / 4), (unsigned)(H / 32));
+    timeit("tiles:  8 rows, 4 waves/blk", 2.0 * bytes, [&] { copy_tiles<8, 4, 0><<<g8, 256>>>(a, b, W, H); });
+    timeit("tiles:  8 rows, 4 waves/blk, nt stores", 2.0 * bytes, [&] { copy_tiles<8, 4, 2><<<g8, 256>>>(a, b, W, H); });
+    timeit("tiles: 16 rows, 4 waves/blk", 2.0 * bytes, [&] { copy_tiles<16, 4, 0><<<g16, 256>>>(a, b, W, H); });
+    timeit("tiles: 16 rows, 4 waves/blk, nt stores", 2.0 * bytes, [&] { copy_tiles<16, 4, 2><<<g16, 256>>>(a, b, W, H); });
+    timeit("tiles: 32 rows, 4 waves/blk", 2.0 * bytes, [&] { copy_tiles<32, 4, 0><<<g32, 256>>>(a, b, W, H); });
+    timeit("tiles: 32 rows, 4 waves/blk, nt stores", 2.0 * bytes, [&] { copy_tiles<32, 4, 2><<<g32, 256>>>(a, b, W, H); });
+    dim3 h16((unsigned)(W / 256), (unsigned)(H / 16));
+    timeit("tiles: 16 rows, 1 wave/blk", 2.0 * bytes, [&] { copy_tiles<16, 1, 0><<<h16, 64>>>(a, b, W, H); });
+    timeit("tiles: 16 rows, 1 wave/blk, nt stores", 2.0 * bytes, [&] { copy_tiles<16, 1, 2><<<h16, 64>>>(a, b, W, H); });
+    dim3 q16((unsigned)(W / 256 / 16), (unsigned)(H / 16));
+    timeit("tiles: 16 rows, 16 waves/blk (a whole row of the array)", 2.0 * bytes, [&] { copy_tiles<16, 16, 0><<<q16, 1024>>>(a, b, W, H); });
+    timeit("tiles: 16 rows, 16 waves/blk, nt stores", 2.0 * bytes, [&] { copy_tiles<16, 16, 2><<<q16, 1024>>>(a, b, W, H); });
   }
   printf("== one direction only\n");
   timeit("fill 1 GiB, 4096 blocks", 1.0 * bytes, [&] { fill_gs<0><<<4096, 256>>>(out, n); });
