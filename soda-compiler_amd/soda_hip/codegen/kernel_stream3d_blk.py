@@ -270,6 +270,10 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   # (by value: __builtin_bit_cast applied directly to the high element of a
   # <2 x float> lvalue stored the LOW element in the ragged-edge path)
   line('DEV unsigned %s_bits(%s v) { return __builtin_bit_cast(unsigned, v); }' % (name, T))
+  # edge rows of a stage of another 4-byte type travel through the LDS array (typed as
+  # the input) as the same BITS (by value, for the reason above)
+  line('template <typename D, typename S> DEV D %s_pun(S v) { return __builtin_bit_cast(D, v); }'
+       % name)
   line('typedef unsigned soda_u4 __attribute__((ext_vector_type(4)));')
 
   def slot(inst, u, back):
@@ -290,14 +294,18 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
 
   def publish(inst, u, s):
     """First `up` and last `down` rows of the plane in window slot s."""
+    def bits(text):
+      if pairs or inst.c_type == in_type:
+        return text
+      return '%s_pun<%s>(%s)' % (name, T, text)
     for k in range(inst.up):
       line('        { %s v;%s *(%s*)&%s[lane * %d] = v; }' % (
-          vec, ''.join(' v[%d] = %s;' % (c, cell(inst.ident, s, k, c))
+          vec, ''.join(' v[%d] = %s;' % (c, bits(cell(inst.ident, s, k, c)))
                        for c in range(C)), vec, edge(inst, u, 'wave + 1', k), C))
     for k in range(inst.down):
       line('        { %s v;%s *(%s*)&%s[lane * %d] = v; }' % (
           vec, ''.join(' v[%d] = %s;' % (
-              c, cell(inst.ident, s, R - inst.down + k, c)) for c in range(C)), vec,
+              c, bits(cell(inst.ident, s, R - inst.down + k, c))) for c in range(C)), vec,
           edge(inst, u, 'wave + 1', inst.up + k), C))
 
   def vmcnt(n):   # s_waitcnt vmcnt(N) only (expcnt and lgkmcnt left at their maxima)
@@ -524,9 +532,12 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
       return 'from_lane_below(%s[%d])' % (row, C + j)
     return 'from_lane_above(%s[%d])' % (row, j - C)
 
-  def edge_read_lines(inst, u):
+  def edge_read_lines(inst, u, visible):
     """The rows of the neighbouring bands a stage instance reads at step u: loads
-    from the published edge rows (LDS) into registers."""
+    from the published edge rows (LDS) into registers.  `visible` = the (instance, slot)
+    keys already declared in the enclosing step's scope (two stages that read one
+    tensor's rows ahead of their arithmetic would declare them twice); returns the
+    lines and the keys they declare."""
     out = []
     wanted = {}
     for src, rel, _ in inst.reads:
@@ -536,29 +547,37 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
       key = (src.ident, slot(src, u, back))
       age = inst.lag - rel[2] - src.lag - src.ready
       wanted[key] = (src, age)
+    wanted = {key: v for key, v in wanted.items() if key not in visible}
     for (ident, s), (src, age) in sorted(wanted.items()):
+      def elem_of(row_vec, c, src=src):
+        if pairs or src.c_type == in_type:
+          return '%s[%d]' % (row_vec, c)
+        return '%s_pun<%s>(%s[%d])' % (name, builtin_type(src.c_type), row_vec, c)
       for k in range(src.down):     # last rows of the band above
         out.append('        const %s xa_v_%s_%d_%d = *(const %s*)&%s[lane * %d];' % (
             vec, ident, s, k, vec, edge(src, u - age, 'wave', src.up + k), C))
         out.append('        const %s xa_%s_%d_%d[%d] = {%s};' % (
             builtin_type(src.c_type), ident, s, k, C, ', '.join(
-                'xa_v_%s_%d_%d[%d]' % (ident, s, k, c) for c in range(C))))
+                elem_of('xa_v_%s_%d_%d' % (ident, s, k), c) for c in range(C))))
       for k in range(src.up):       # first rows of the band below
         out.append('        const %s xb_v_%s_%d_%d = *(const %s*)&%s[lane * %d];' % (
             vec, ident, s, k, vec, edge(src, u - age, 'wave + 2', k), C))
         out.append('        const %s xb_%s_%d_%d[%d] = {%s};' % (
             builtin_type(src.c_type), ident, s, k, C, ', '.join(
-                'xb_v_%s_%d_%d[%d]' % (ident, s, k, c) for c in range(C))))
-    return out
+                elem_of('xb_v_%s_%d_%d' % (ident, s, k), c) for c in range(C))))
+    return out, set(wanted)
 
   for u in range(period):
     line('    {  // unrolled step %d' % u)
     edges_done = set()
+    in_step_scope = set()      # edge rows declared at the step's own level
     if not ring:      # the first level's rows, ahead of the input plane's part
       ahead = [i for i in insts if i.stage is not None]
       for inst in ahead[:1]:
         edges_done.add(id(inst))
-        for text in edge_read_lines(inst, u):
+        lines, keys = edge_read_lines(inst, u, in_step_scope)
+        in_step_scope |= keys
+        for text in lines:
           line(text)
     for inst_index, inst in enumerate(insts):
       if inst_index:
@@ -607,11 +626,13 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
         later = [i for i in insts[insts.index(inst) + 1:] if i.stage is not None]
         if later:                           # (step scope: the next block uses them)
           edges_done.add(id(later[0]))
-          for text in edge_read_lines(later[0], u):
+          lines, keys = edge_read_lines(later[0], u, in_step_scope)
+          in_step_scope |= keys
+          for text in lines:
             line(text)
       line('      {')
       if id(inst) not in edges_done:
-        for text in edge_read_lines(inst, u):
+        for text in edge_read_lines(inst, u, in_step_scope)[0]:
           line(text)
       if pairs:
         ctype = 'pk2'

@@ -588,3 +588,37 @@ def test_generated_cpp_host_multi_gpu_entry_compiles(tmp_path):
   assert run_sodac(os.path.join(SAMPLES, 'denoise2d.soda'), '--hip-host-cpp',
                    str(src2)).returncode == 0
   assert '_multi_gpu' not in src2.read_text()
+
+
+ROUND4_FUZZ_FINDS = {
+    # edge rows of an int32 stage through the LDS array of a uint32 input (the block form
+    # read them back with a narrowing initialiser: a compile error)
+    'ops7222': """kernel: ops7222
+burst width: 512
+unroll factor: 2
+iterate: 2
+input uint32: a(32, 32, *)
+local int32: m(0, 0, 0) = a(0, 0, 0) - (a(0, 1, 1) ^ a(0, -1, -1)) + (a(0, 0, 1) >= a(0, 1, 1)) + (-a(-1, 1, -1))
+output uint32: out(0, 0, 0) = m(0, 0, 0) - (-m(-1, -1, 1)) + (m(1, 0, -1) % 3)
+""",
+    # two stages that read the INPUT's edge rows ahead of their arithmetic (block form at
+    # depth 1, register prefetch): the rows were declared twice in the step's scope
+    'st7327': """kernel: st7327
+burst width: 512
+unroll factor: 4
+iterate: 2
+input float: in0(64, 64, *)
+local float: loc0(0, 0, 0) = (in0(0, 0, 0) + in0(1, 1, 2) * 0.25f - in0(1, 0, -1) + in0(0, 0, -1) - in0(-1, 0, -1)) * 0.125f
+local float: loc1(0, 0, 0) = loc0(0, 0, 0) + loc0(2, 1, 1) + in0(-1, -1, 2)
+output float: out(0, 0, 0) = in0(0, 0, 0) - loc1(1, 0, -2) * 0.125f - in0(-1, -2, 2) * 0.5f
+"""}
+
+
+@pytest.mark.parametrize('name', sorted(ROUND4_FUZZ_FINDS))
+def test_programs_the_round4_fuzzing_found(name, tmp_path):
+  """Two 3-D programs of tools/fuzz_gpu.py (fresh seeds, round 4) whose block-form
+  kernels did not compile; they build now (and run against the oracle in the GPU suite)."""
+  spec = specmod.spec_from_stencil(frontend.loads(ROUND4_FUZZ_FINDS[name]))
+  text, table = kernel.generate(spec)
+  assert any(k.get('stack') for k in table), [k['name'] for k in table]
+  kernel.compile_to_code_object(text, str(tmp_path / 'k.hsaco'))

@@ -157,3 +157,15 @@ def test_random_program_many_iterations(seed):
   the wave-pipelined and packed forms the generator picks for chains that do not
   fit one wavefront's registers."""
   run_case('deep%d' % seed, (400, 700), np.random.default_rng(5000 + seed))
+
+
+@pytest.mark.parametrize('name', ['ops7222', 'st7327'])
+def test_programs_the_round4_fuzzing_found(name):
+  """The two 3-D programs whose block-form kernels did not compile before round 4
+  (tests/test_codegen.py: ROUND4_FUZZ_FINDS - an int32 stage's edge rows through a
+  uint32-typed LDS array; two stages reading one tensor's edge rows ahead), every depth
+  split against the oracle (no reference fixture: they come from fresh fuzzing seeds)."""
+  from test_codegen import ROUND4_FUZZ_FINDS
+  PROGRAMS[name] = dict(text=ROUND4_FUZZ_FINDS[name], iterate=2, dim=3)
+  table = run_case(name, (40, 80, 150), np.random.default_rng(16000))
+  assert any(k.get('stack') for k in table)
