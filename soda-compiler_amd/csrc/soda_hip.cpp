@@ -86,8 +86,6 @@ struct soda_hip_plan {
   // chunks)
   int chunk_rows_min = 8;
   int wgs_per_cu_cap = 0;            // SODA_HIP_WGS_PER_CU, for tuning (see make_launch)
-  bool chunk_tie_short = false;      // SODA_HIP_CHUNK_TIE_SHORT, for tuning
-  bool chunk_by_time = false;        // SODA_HIP_CHUNK_BY_TIME, for tuning
   // soda_hip_plan_set_out_final_only: `out` is written by the LAST launch of a sweep
   // only; the launches before it alternate between scratch and scratch_b
   bool out_final_only = false;
@@ -377,7 +375,6 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
         out->lds_bytes = 160u * 1024u / (unsigned)(cap + 1) + 1024u;
       }
       int64_t best = tile, best_cost = -1;
-      double best_time = -1;
       const double footprint = footprint_of(plan, args);
       const int64_t shortest = plan->chunk_rows_min;   // 8; SODA_HIP_CHUNK_MIN
       for (int64_t chunk = shortest;
@@ -388,22 +385,10 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
         const int64_t cost = rounds * (chunk + desc.fill_rows);
         // among equal step counts the LONGEST chunk: fewer workgroups, fewer fill rows
         // fetched (jacobi3d box 504^3: 5 chunks of 104 planes in one round and 11 of
-        // 48 in two both walk 112 steps; the long ones read 8 % less)
-        if (plan->chunk_by_time) {
-          // (tuning) the priced time instead of the step count: the step time depends
-          // on how many workgroups share a CU and, on arrays beyond the caches, on the
-          // bytes they move together
-          const double t = (double)cost * step_seconds(plan, k, (double)blocks, footprint);
-          if (t > 0) {
-            if (best_time < 0 || t < best_time * (1 - 1e-9) ||
-                (t <= best_time * (1 + 1e-9) && !plan->chunk_tie_short)) {
-              best_time = t;
-              best = chunk;
-            }
-            continue;
-          }
-        }
-        if (best_cost < 0 || cost < best_cost || (cost == best_cost && !plan->chunk_tie_short)) {
+        // 48 in two both walk 112 steps; the long ones read 8 % less).  (Round 3 also
+        // measured the chunk by its PRICED time - cfg4 +16 %, cfg2 +7 % - and the shortest
+        // chunk on ties - cfg5 +3 %: DESIGN.md 4.3; both switches are gone.)
+        if (best_cost < 0 || cost <= best_cost) {
           best_cost = cost;
           best = chunk;
         }
@@ -1125,8 +1110,6 @@ int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* progra
   }
   if (const char* env = tuning_env("SODA_HIP_CHUNK_ROWS")) pl->chunk_rows_override = atoi(env);
   if (const char* env = tuning_env("SODA_HIP_WGS_PER_CU")) pl->wgs_per_cu_cap = atoi(env);
-  if (tuning_env("SODA_HIP_CHUNK_TIE_SHORT")) pl->chunk_tie_short = true;
-  if (tuning_env("SODA_HIP_CHUNK_BY_TIME")) pl->chunk_by_time = true;
   if (const char* env = tuning_env("SODA_HIP_CHUNK_MIN"))
     pl->chunk_rows_min = std::max(4, atoi(env));
   *plan = pl;

@@ -92,8 +92,12 @@ BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300, nt=4, mask_loads=1
 # and the next 64-byte boundary (unspecified by contract, read by nobody) are stored
 # along, in launches beyond the Infinity Cache (2; 1 = always: boxes of 232^3 .. 336^3
 # +1 %): cfg5 with this form alone 4.95 -> 4.79 ms, box 496 225 -> 210 us, 440 172 -> 156
+# lean_fill: the levels a chunk's first steps do not need are skipped there (a second,
+# guarded copy of the row loop for the trips at a chunk's ends; round 4): cfg5 with this
+# form alone 4.81 -> 4.66 ms, per launch box 400 130.5 -> 125.6 us, 256 55.0 -> 48.8,
+# 224 42.8 -> 37.3 (profiles/r04_blk_lean_fill.txt)
 BLOCK_3D_RING_OPTIONS = dict(stack=8, prefetch=0, ring=2, vgpr_budget=300, nt=4,
-                             mask_loads=1, wide_stores=2)
+                             mask_loads=1, wide_stores=2, lean_fill=1)
 # ... for programs light enough on arithmetic: jacobi3d (weight 7) 417 us per
 # depth-4 launch against 2 x 374 us at depth 2, heat3d (15) 622 us against
 # 2 x 411 us; heavier programs are VALU-bound at depth 2 already

@@ -551,9 +551,10 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
     else:
       emit_line('  const bool partial = !(x >= st_lo && x + %d <= st_hi) && (%s);' % (
           C, ' || '.join('(x + %d >= st_lo && x + %d < st_hi)' % (c, c) for c in range(C))))
-    # (rows of 4 GiB or more: the branch-free store's 32-bit offsets do not reach)
+    # (rows of 2 GiB or more: the branch-free store's buffer resource takes a signed
+    # 32-bit size and 32-bit lane offsets; such rows keep the guarded path)
     emit_line('  const bool ragged = __builtin_amdgcn_ballot_w64(partial) != 0 || '
-              'a.dims[0] * %d >= 0xfffffff0ll;' % elem)
+              'a.dims[0] * %d >= 0x7ffffff0ll;' % elem)
     emit_line('  if (!interior) %s_strip<false, true>(a, xs, x, y0, y1);' % name)
     emit_line('  else if (ragged) %s_strip<true, true>(a, xs, x, y0, y1);' % name)
     if nt_auto:

@@ -96,7 +96,7 @@ ALIGN_OUT = 16      # cells: output tiles start and end on 64-byte pieces
 
 def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
          vgpr_budget=250, ring=0, pairs=0, stamps=0, mask_loads=0, nt=0,
-         wide_stores=0):
+         wide_stores=0, lean_fill=0):
   """Returns (text, kernel table entry).
 
   `prefetch` = input planes loaded ahead into REGISTERS (R*C VGPRs each);
@@ -145,6 +145,16 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   A hand-ordered instruction stream for the arithmetic (one `asm` per VALU instruction,
   cells interleaved) was built and measured twice: it paid only for heavy programs and
   packed pair-rows beat it there, so it is gone.
+  `lean_fill` = 1 (ring form): a chunk of n planes walks n + fill steps, and in the first
+  and last of them some levels compute planes no stored cell depends on (depth 4: 4 n +
+  32 level-planes computed, 4 n + 12 needed).  The row loop is emitted twice: trips in
+  which every level is needed at every step run the branch-free body; the trips at a
+  chunk's two ends run a copy whose levels sit under wave-uniform conditions (the parts
+  of a step are fenced apart anyway, so a scalar branch per part costs little there).
+  Memory operations are NOT skipped - the ring's counted waits need the same loads and
+  stores every step (stores of skipped planes are dropped by the record count as always)
+  - and a skipped level's edge rows are read only by cells that are skipped or unneeded
+  themselves.  Round 3 measured level skipping with the branches in EVERY step: +14 %.
   `stamps` = device address of a debug buffer (tools/blk_stamps.py only): the
   wavefront sums the shader cycles (s_memtime) it spends in each part of a step -
   input plane, each stage instance, the barrier - and lane 0 writes the sums there;
@@ -191,6 +201,19 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     raise NotFusable('ring and register prefetch exclude each other')
   insts, final = build_chain(spec, depth, prefetch)
   source = insts[0]
+  # planes of an instance that the chunk's output planes [z0, z1) depend on:
+  # [z0 - need_lo, z1 + need_hi)
+  for inst in insts:
+    inst.need_lo = inst.need_hi = None
+  final.need_lo = final.need_hi = 0
+  for inst in reversed(insts):
+    if inst.need_lo is None:
+      continue
+    for src, rel, _ in inst.reads:
+      lo_need, hi_need = inst.need_lo - rel[2], inst.need_hi + rel[2]
+      src.need_lo = lo_need if src.need_lo is None else max(src.need_lo, lo_need)
+      src.need_hi = hi_need if src.need_hi is None else max(src.need_hi, hi_need)
+  lean_fill = bool(lean_fill) and bool(ring) and not stamps
   rows_per_load = 16 // (C * elem)     # a 16-byte-per-lane load covers this many rows
   if ring and (rows_per_load < 1 or R % rows_per_load):
     raise NotFusable('ring: %d rows per load do not divide %d rows' % (rows_per_load, R))
@@ -483,8 +506,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
       line('      { const unsigned long long now = __builtin_readcyclecounter(); '
            'soda_t[%d] += now - soda_prev; soda_prev = now; }' % k)
       line('      __builtin_amdgcn_sched_barrier(0);')
-  line('  for (i64 n = 0; n < steps; n += %d, head += %d) {' % (period, period))
-
   def out_cell(r, c):
     if pairs:
       return 'out_tile[%d][%d][%d]' % (r % RP, c, r // RP)
@@ -567,109 +588,149 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
                 elem_of('xb_v_%s_%d_%d' % (ident, s, k), c) for c in range(C))))
     return out, set(wanted)
 
-  for u in range(period):
-    line('    {  // unrolled step %d' % u)
-    edges_done = set()
-    in_step_scope = set()      # edge rows declared at the step's own level
-    if not ring:      # the first level's rows, ahead of the input plane's part
-      ahead = [i for i in insts if i.stage is not None]
-      for inst in ahead[:1]:
-        edges_done.add(id(inst))
-        lines, keys = edge_read_lines(inst, u, in_step_scope)
-        in_step_scope |= keys
-        for text in lines:
-          line(text)
-    for inst_index, inst in enumerate(insts):
-      if inst_index:
-        stamp(inst_index - 1)
-      if inst.stage is None and ring:
-        s = slot(inst, u, 0)
-        # plane head+u was issued `ring` steps ago; since then this wavefront has
-        # issued ring-1 planes of loads and `ring` steps of (at least) R stores
-        wait = (ring - 1) * ring_loads + ring * R
-        # (the ragged instantiation stores column by column)
-        ragged_wait = (ring - 1) * ring_loads + ring * R * C
-        line('      __builtin_amdgcn_s_waitcnt(RAGGED ? %d : %d);  // vmcnt(%d / %d)' % (
-            vmcnt(min(63, ragged_wait)), vmcnt(wait), min(63, ragged_wait), wait))
-        line('      { %s t[%d][%d];' % (T, R, C))
-        line('        soda_ring_read_%s(&in_ring[%d][wave][0][lane * %d], %s);' % (
-            name, u % ring, C, ', '.join('t[%d][%d]' % (r, c)
-                                         for r in range(R) for c in range(C))))
-        for r in range(R):
-          line('        ' + ' '.join('%s = t[%d][%d];' % (cell(inst.ident, s, r, c), r, c)
-                                     for c in range(C)))
-        line('      }')
-        ring_load(u % ring, 'head + %d' % (u + ring), '      ')
-        if inst.up or inst.down:
-          publish(inst, u, s)
-        continue
-      if inst.stage is None:
-        s = slot(inst, u, 0)
-        line('      { i64 zz = head + %d; if (zz > D - 1) zz = D - 1;' % u)
-        line('        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
-             'rsrc((void*)(g_in + zz * plane), 0, (int)ld_plane_bytes, 0x27000);')
-        for r in range(R):
-          line('        { const %s v = __builtin_bit_cast(%s, __builtin_amdgcn_raw_'
-               'buffer_load_%s(rs, %s, (unsigned)(%d * W * %d), %d));%s }' % (
-                   vec, vec, suffix, 'ld_lane_byte', r, elem, ld_aux,
-                   ''.join(
-                       ' %s = v[%d];' % (cell(inst.ident, s, r, c), c)
-                       for c in range(C))))
-        line('      }')
-        if inst.up or inst.down:    # the plane that "exists" from this step on
-          publish(inst, u, slot(inst, u, inst.ready))
-        continue
-      stage = inst.stage
-      ctype = builtin_type(inst.c_type)
-      by_name = {(n, rel): src for src, rel, n in inst.reads}
-      if not ring:      # the next level's rows, ahead of this one's
-        later = [i for i in insts[insts.index(inst) + 1:] if i.stage is not None]
-        if later:                           # (step scope: the next block uses them)
-          edges_done.add(id(later[0]))
-          lines, keys = edge_read_lines(later[0], u, in_step_scope)
+  def needed(inst, u):
+    """Wave-uniform condition under which `inst` has to run at unrolled step u of the
+    trip that starts at step n: its plane head + u - lag lies in [z0 - need_lo,
+    z1 + need_hi)."""
+    first = lo[2] + inst.lag - inst.need_lo
+    last = lo[2] + inst.lag + inst.need_hi          # n + u < span + last
+    parts = ['n + %d >= %d' % (u, first)] if first > 0 else []
+    parts.append('n + %d < span + %d' % (u, last))
+    return ' && '.join(parts), first, last
+
+  def emit_trip(guarded):
+    for u in range(period):
+      line('    {  // unrolled step %d' % u)
+      edges_done = set()
+      in_step_scope = set()      # edge rows declared at the step's own level
+      if not ring:      # the first level's rows, ahead of the input plane's part
+        ahead = [i for i in insts if i.stage is not None]
+        for inst in ahead[:1]:
+          edges_done.add(id(inst))
+          lines, keys = edge_read_lines(inst, u, in_step_scope)
           in_step_scope |= keys
           for text in lines:
             line(text)
-      line('      {')
-      if id(inst) not in edges_done:
-        for text in edge_read_lines(inst, u, in_step_scope)[0]:
-          line(text)
-      if pairs:
-        ctype = 'pk2'
-      if inst.final:
-        line('        %s out_tile[%d][%d];' % (ctype, RP, C))
-      for r in range(RP):
-        for c in range(C):
-          def load(tensor, rel, u=u, r=r, c=c, inst=inst, by_name=by_name):
-            return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, r, c)
-          target = ('out_tile[%d][%d]' % (r, c)) if inst.final else \
-              '%s[%d][%d][%d]' % (inst.ident, slot(inst, u, 0), r, c)
-          cell_assignment(stage, target, load, line, '        ')
-      if inst.up or inst.down:
-        publish(inst, u, slot(inst, u, 0))
-      if inst.final:
-        line('        const i64 z = head + %d;' % (u - L))
-        line('        const bool z_ok = z >= z0 && z < z1;')
-        line('        const unsigned rows_now = z_ok ? st_rows : 0u;')
-        line('        %s* const out_plane = g_out + (z_ok ? z : z0) * plane;' % T)
-        for r in range(R):
-          line('        { const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
-               'rsrc((void*)out_plane, 0, (rows_now >> %d) & 1u ? (int)plane_bytes : 0, '
-               '0x27000);' % r)
-          line('          if (!RAGGED) { %s v;%s __builtin_amdgcn_raw_buffer_store_%s('
-               '__builtin_bit_cast(%s, v), rs, st_voff, (unsigned)(%d * W * %d), %s); }' % (
-                   vec, ''.join(' v[%d] = %s;' % (c, out_cell(r, c))
-                                for c in range(C)), suffix, buf_type, r, elem, st_aux))
-          line('          else {%s }' % ''.join(
-              ' __builtin_amdgcn_raw_buffer_store_b32(%s_bits(%s), rs, st_voff%d, '
-              '(unsigned)(%d * W * %d), %s);' % (name, out_cell(r, c), c, r, elem, st_aux)
-              for c in range(C)))
+      for inst_index, inst in enumerate(insts):
+        if inst_index:
+          stamp(inst_index - 1)
+        if inst.stage is None and ring:
+          s = slot(inst, u, 0)
+          # plane head+u was issued `ring` steps ago; since then this wavefront has
+          # issued ring-1 planes of loads and `ring` steps of (at least) R stores
+          wait = (ring - 1) * ring_loads + ring * R
+          # (the ragged instantiation stores column by column)
+          ragged_wait = (ring - 1) * ring_loads + ring * R * C
+          line('      __builtin_amdgcn_s_waitcnt(RAGGED ? %d : %d);  // vmcnt(%d / %d)' % (
+              vmcnt(min(63, ragged_wait)), vmcnt(wait), min(63, ragged_wait), wait))
+          line('      { %s t[%d][%d];' % (T, R, C))
+          line('        soda_ring_read_%s(&in_ring[%d][wave][0][lane * %d], %s);' % (
+              name, u % ring, C, ', '.join('t[%d][%d]' % (r, c)
+                                           for r in range(R) for c in range(C))))
+          for r in range(R):
+            line('        ' + ' '.join('%s = t[%d][%d];' % (cell(inst.ident, s, r, c), r, c)
+                                       for c in range(C)))
+          line('      }')
+          ring_load(u % ring, 'head + %d' % (u + ring), '      ')
+          if inst.up or inst.down:
+            publish(inst, u, s)
+          continue
+        if inst.stage is None:
+          s = slot(inst, u, 0)
+          line('      { i64 zz = head + %d; if (zz > D - 1) zz = D - 1;' % u)
+          line('        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
+               'rsrc((void*)(g_in + zz * plane), 0, (int)ld_plane_bytes, 0x27000);')
+          for r in range(R):
+            line('        { const %s v = __builtin_bit_cast(%s, __builtin_amdgcn_raw_'
+                 'buffer_load_%s(rs, %s, (unsigned)(%d * W * %d), %d));%s }' % (
+                     vec, vec, suffix, 'ld_lane_byte', r, elem, ld_aux,
+                     ''.join(
+                         ' %s = v[%d];' % (cell(inst.ident, s, r, c), c)
+                         for c in range(C))))
+          line('      }')
+          if inst.up or inst.down:    # the plane that "exists" from this step on
+            publish(inst, u, slot(inst, u, inst.ready))
+          continue
+        stage = inst.stage
+        ctype = builtin_type(inst.c_type)
+        by_name = {(n, rel): src for src, rel, n in inst.reads}
+        if not ring:      # the next level's rows, ahead of this one's
+          later = [i for i in insts[insts.index(inst) + 1:] if i.stage is not None]
+          if later:                           # (step scope: the next block uses them)
+            edges_done.add(id(later[0]))
+            lines, keys = edge_read_lines(later[0], u, in_step_scope)
+            in_step_scope |= keys
+            for text in lines:
+              line(text)
+        line('      {')
+        if pairs:
+          ctype = 'pk2'
+        if inst.final:
+          line('        %s out_tile[%d][%d];' % (ctype, RP, C))
+        if guarded:
+          # (a skipped final level still issues its stores - the counted waits need them
+          # - with a record count of 0: its plane lies outside [z0, z1))
+          if inst.final:
+            for r in range(RP):
+              line('        ' + ' '.join('out_tile[%d][%d] = %s;' % (
+                  r, c, 'pk2{0.0f, 0.0f}' if pairs else '0') for c in range(C)))
+          line('        if (%s) {' % needed(inst, u)[0])
+        if id(inst) not in edges_done:
+          for text in edge_read_lines(inst, u, in_step_scope)[0]:
+            line(text)
+        for r in range(RP):
+          for c in range(C):
+            def load(tensor, rel, u=u, r=r, c=c, inst=inst, by_name=by_name):
+              return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, r, c)
+            target = ('out_tile[%d][%d]' % (r, c)) if inst.final else \
+                '%s[%d][%d][%d]' % (inst.ident, slot(inst, u, 0), r, c)
+            cell_assignment(stage, target, load, line, '        ')
+        if inst.up or inst.down:
+          publish(inst, u, slot(inst, u, 0))
+        if guarded:
           line('        }')
-      line('      }')
-    stamp(len(insts) - 1)
-    line('    }')
-    line('    %s();' % ('soda_lds_barrier' if ring else 'soda_block_barrier'))
-    stamp(len(insts))
+        if inst.final:
+          line('        const i64 z = head + %d;' % (u - L))
+          line('        const bool z_ok = z >= z0 && z < z1;')
+          line('        const unsigned rows_now = z_ok ? st_rows : 0u;')
+          line('        %s* const out_plane = g_out + (z_ok ? z : z0) * plane;' % T)
+          for r in range(R):
+            line('        { const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
+                 'rsrc((void*)out_plane, 0, (rows_now >> %d) & 1u ? (int)plane_bytes : 0, '
+                 '0x27000);' % r)
+            line('          if (!RAGGED) { %s v;%s __builtin_amdgcn_raw_buffer_store_%s('
+                 '__builtin_bit_cast(%s, v), rs, st_voff, (unsigned)(%d * W * %d), %s); }' % (
+                     vec, ''.join(' v[%d] = %s;' % (c, out_cell(r, c))
+                                  for c in range(C)), suffix, buf_type, r, elem, st_aux))
+            line('          else {%s }' % ''.join(
+                ' __builtin_amdgcn_raw_buffer_store_b32(%s_bits(%s), rs, st_voff%d, '
+                '(unsigned)(%d * W * %d), %s);' % (name, out_cell(r, c), c, r, elem, st_aux)
+                for c in range(C)))
+            line('        }')
+        line('      }')
+      stamp(len(insts) - 1)
+      line('    }')
+      line('    %s();' % ('soda_lds_barrier' if ring else 'soda_block_barrier'))
+      stamp(len(insts))
+
+  stages = [i for i in insts if i.stage is not None]
+  line('  i64 n = 0;')
+  if lean_fill:
+    firsts = [needed(i, 0)[1] for i in stages]
+    lasts = [needed(i, 0)[2] for i in stages]
+    lean_from = -(-max(firsts + [0]) // period) * period
+    line('  // trips at the chunk\'s start: levels run from the step their plane is needed at')
+    line('  for (; n < %d && n < steps; n += %d, head += %d) {' % (lean_from, period, period))
+    emit_trip(True)
+    line('  }')
+    line('  // every level needed at every step of the trip: the branch-free body')
+    line('  for (; n + %d <= span + %d; n += %d, head += %d) {' % (period, min(lasts), period,
+                                                                 period))
+    emit_trip(False)
+    line('  }')
+    line('  // trips at the chunk\'s end')
+  line('  for (; n < steps; n += %d, head += %d) {' % (period, period))
+  emit_trip(lean_fill)
   line('  }')
   if stamps:
     line('  if (lane == 0) {')
@@ -757,6 +818,8 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     entry['nt'] = int(nt)
   if mask_loads:
     entry['mask_loads'] = 1
+  if lean_fill:
+    entry['lean_fill'] = 1
   if wide_stores:
     entry['wide_stores'] = int(wide_stores)
   return '\n'.join(o) + '\n', entry

@@ -202,6 +202,10 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
   # input planes through the two-slot LDS ring
   assert blk[0]['min_extent'] == [128, 64]
   assert (blk[0]['prefetch'], blk[0]['ring']) == (0, 2)
+  # the trips at a chunk's ends skip the levels nobody needs yet (a guarded copy of the
+  # row loop; the steady trips keep the branch-free body)
+  assert blk[0]['lean_fill'] == 1 and "// trips at the chunk's start" in text
+  assert 'if (n + 0 >= 2 && n + 0 < span + 8) {' in text
   # launches beyond the Infinity Cache store around the caches: an instantiation of
   # its own, chosen by the kernel's entry from the box it is given
   assert blk[0]['nt'] == 4 and '_band<false, true>(' in text

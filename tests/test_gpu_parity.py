@@ -296,6 +296,7 @@ def test_3d_wave_pipelined_forms_on_heat3d(options):
     ('heat3d', dict(deep3d='blk')),                        # ring + packed pair-rows
     ('heat3d', dict(deep3d='blk', blk_pairs=0)),           # ring, scalar arithmetic
     ('jacobi3d', dict(deep3d='blk', blk_mask_loads=0)),    # unmasked global_load_lds ring
+    ('jacobi3d', dict(deep3d='blk', blk_lean_fill=0)),     # every level at every step
     # row segments stored in whole 64-byte pieces (shipped: only in launches beyond the
     # Infinity Cache - the full-size tests; forced on here), and never
     ('jacobi3d', dict(deep3d='blk', blk_wide_stores=1)),
