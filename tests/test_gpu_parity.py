@@ -262,10 +262,10 @@ def test_3d_wave_pipelined_depth_4(app, shape, iterate):
   assert timing['max_depth'] == 4, timing
 
 
-@pytest.mark.parametrize('options', [dict(), dict(wp_loader=1, wp_waves_per_eu=3),
-                                     dict(wp_split=1), dict(wp_prefetch=1),
-                                     dict(wp_pairs=0), dict(wp_pairs=1, wp_waves_per_eu=3),
-                                     dict(wp_pairs=1, wp_rows=12)])
+@pytest.mark.parametrize('options', [dict(), dict(wp_prefetch=1), dict(wp_pairs=0),
+                                     dict(wp_pairs=1, wp_waves_per_eu=3)] + (
+    [dict(wp_loader=1, wp_waves_per_eu=3), dict(wp_split=1), dict(wp_pairs=1, wp_rows=12)]
+    if os.environ.get('SODA_TEST_ALL_FORMS') else []))
 def test_3d_wave_pipelined_forms_on_heat3d(options):
   """The depth-4 generator on heat3d (FMA-sensitive expression) in its optional
   forms: packed pair-rows (the default for float programs) and scalar,
@@ -299,10 +299,8 @@ def test_3d_wave_pipelined_forms_on_heat3d(options):
     ('jacobi3d', dict(deep3d='blk', blk_lean_fill=0)),     # every level at every step
     # row segments stored in whole 64-byte pieces (shipped: only in launches beyond the
     # Infinity Cache - the full-size tests; forced on here), and never
-    ('jacobi3d', dict(deep3d='blk', blk_wide_stores=1)),
     ('heat3d', dict(deep3d='blk', blk_wide_stores=1, blk_nt=2)),
     ('jacobi3d', dict(deep3d='blk', blk_wide_stores=0)),
-    ('jacobi3d', dict(deep3d='blk', blk_stack=4, blk_prefetch=0)),
     # packed pair-rows for a light program; four bands per workgroup
     ('jacobi3d', dict(deep3d='blk', blk_pairs=1)),
     ('heat3d', dict(deep3d='blk', blk_stack=4, blk_prefetch=0, blk_pairs=1, blk_ring=2))])
