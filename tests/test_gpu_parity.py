@@ -1425,3 +1425,40 @@ def test_run_on_data_in_the_reference_dram_layout(fixture):
     assert np.array_equal(got[sl], want[name][sl]) and want[name][sl].size
   prog.close()
   prog.blob.unload()
+
+
+def test_streaming_launches_of_the_depth1_kernel_are_capped_per_cu():
+  """soda_hip_kernel.stream_wgs_per_cu (ABI 5): a launch of the seam-free depth-1 kernel
+  whose box does not fit the Infinity Cache runs at most two workgroups per CU - fewer
+  workgroups on longer chunks - while a cache-resident one fills the chip; results are the
+  same either way (the cap only changes the chunk length)."""
+  import re
+  import subprocess
+  import sys
+  from conftest import ROOT
+  code = (
+      'import sys, numpy as np\n'
+      'sys.path[:0] = [%r, %r, %r]\n'
+      'import gpu_util\n'
+      'from soda_hip.runtime import host\n'
+      'prog = gpu_util.open_prebuilt("jacobi2d")\n'
+      'prog.set_max_depth(1)\n'
+      'for n in (3072, 12288):\n'
+      '  a = host.DeviceArray(n * n * 4); a.zero()\n'
+      '  b = host.DeviceArray(n * n * 4); b.zero()\n'
+      '  prog.sweep_timed([a.ptr], [b.ptr], [n, n], 1, warmup=0, repeats=1)\n'
+      '  a.free(); b.free()\n' % (ROOT, os.path.join(ROOT, 'soda-compiler_amd'),
+                                   os.path.join(ROOT, 'tests')))
+  r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True,
+                     env=dict(os.environ, SODA_HIP_TUNING='1', SODA_HIP_LAUNCH_TRACE='1'),
+                     timeout=300)
+  assert r.returncode == 0, r.stderr[-2000:]
+  launches = re.findall(r'launch\s+\d+ jacobi2d_fused_k1\s+[\d.]+ us \(model\s+[\d.]+\)  box (\d+) x '
+                        r'(\d+) x \d+  grid (\d+) x (\d+) x \d+  chunk (\d+)', r.stderr)
+  assert len(launches) == 2, r.stderr[-2000:]
+  entry = [k for k in program('jacobi2d').kernels if k['name'] == 'jacobi2d_fused_k1'][0]
+  assert entry['stream_wgs_per_cu'] == 2 and entry['exact'] == 1
+  cus = host.device_info(0)['compute_units']
+  small, big = [(int(gx) * int(gy), int(chunk)) for _, _, gx, gy, chunk in launches]
+  assert small[0] > 2 * cus          # 3072^2 (72 MiB in + out): the chip is filled
+  assert big[0] <= 2 * cus and big[1] > 4 * small[1]      # 12288^2: <= 2 per CU, long chunks
