@@ -196,7 +196,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
   # overlapping strips), a scheduling fence per row, loaded rows kept packed - see emit_body
   flat = steady and C * elem in (4, 8, 16)
   for inst in insts:
-    inst.edges = 0      # columns beyond the strip, per side, that readers ask for
+    inst.edges = dict(lo=0, hi=0)    # columns beyond the strip that readers ask for, per side
   if exact:
     # which instances are needed beyond the strip (C columns on either side, held by the
     # first and the last lane): those read across lanes - and what THEY are computed
@@ -205,8 +205,9 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
     # loaded, blur_x's computed from them)
     for inst in reversed(insts):
       for src, rel, _ in inst.reads:
-        src.edges = max(src.edges, abs(rel[0]))
-      if inst.edges and inst.stage is not None:
+        src.edges['lo'] = max(src.edges['lo'], -rel[0])
+        src.edges['hi'] = max(src.edges['hi'], rel[0])
+      if any(inst.edges.values()) and inst.stage is not None:
         if not stage_edges:
           # (blur: blur_y reads blur_x across lanes.  Computing blur_x beyond the strip
           # works - bit-exact, `stage_edges=1` - and is no faster than overlapping
@@ -216,7 +217,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
           if rel[0]:
             raise NotFusable('seam-free strips: stage %s is read across lanes and reads '
                              '%s across lanes itself' % (inst.tensor, src.tensor))
-          src.edges = max(src.edges, inst.edges)
+          for side in ('lo', 'hi'):
+            src.edges[side] = max(src.edges[side], inst.edges[side])
   # Rotation period: the row loop is unrolled `period` times so that every
   # window's "shift" is a renaming; each keep must divide it.  Keeping MORE rows
   # than needed is always legal, so keeps are rounded up to divisors of the
@@ -241,7 +243,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
     inst.keep = keep
   # register budget: every retained row costs C VGPRs per lane (2C for 8-byte
   # types); past ~224 the kernel drops below two waves per SIMD and then spills
-  est_vgprs = sum(inst.keep * (cols + 2 * inst.edges) *
+  est_vgprs = sum(inst.keep * (cols + sum(inst.edges.values())) *
                   max(1, specmod.ELEM_SIZE[inst.c_type] // 4) for inst in insts) + \
       4 * cols + 16
   if est_vgprs > vgpr_budget:
@@ -322,7 +324,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
     elif inst.keep:
       emit_line('  %s %s[%d][%d];' % (builtin_type(inst.c_type), inst.ident,
                                      inst.keep, C))
-    if inst.edges:
+    if any(inst.edges.values()):
       # seam-free strips: column k left of the strip (edge_lo: column xs - 1 - k) and
       # right of it (edge_hi: xs + 64 C + k) of every live row - what a lane below the
       # first / above the last one would hold - in every lane (lanes 0 and 63 use them).
@@ -330,16 +332,18 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
       # read by two DPP moves is copied first, and the scheduler hoists that copy to the
       # top of the row loop, where it waits for the load issued last
       for side in ('lo', 'hi'):
-        emit_line('  %s edge_%s_%s[%d][%d];' % (builtin_type(inst.c_type), side, inst.ident,
-                                               inst.keep, inst.edges))
+        if inst.edges[side]:
+          emit_line('  %s edge_%s_%s[%d][%d];' % (builtin_type(inst.c_type), side, inst.ident,
+                                                 inst.keep, inst.edges[side]))
   # windows start as zeros so that the prologue computes on defined values
   for inst in insts:
     for r in range(inst.keep):
       emit_line('  ' + ' '.join('%s[%d][%d] = 0;' % (inst.ident, r, c)
                                 for c in range(C)))
-      for side in ('lo', 'hi') if inst.edges else ():
-        emit_line('  ' + ' '.join('edge_%s_%s[%d][%d] = 0;' % (side, inst.ident, r, c)
-                                  for c in range(inst.edges)))
+      for side in ('lo', 'hi'):
+        if inst.edges[side]:
+          emit_line('  ' + ' '.join('edge_%s_%s[%d][%d] = 0;' % (side, inst.ident, r, c)
+                                    for c in range(inst.edges[side])))
   # (seam-free strips: EVERY lane loads the edge columns, one element per column and side
   # at a wave-uniform address: no branch in the row loop - under a branch the compiler
   # waits for all loads in flight at the join.  Clamped into the row where the array has
@@ -364,7 +368,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
     if 0 <= j < C:
       return '%s[%d]' % (row, j)
     if exact:       # the first / last lane take the column from the strip's edge loads
-      assert src.edges
+      assert src.edges['lo' if j < 0 else 'hi'] >= (-j if j < 0 else j - C + 1)
       if j < 0:
         return 'from_lane_below_or(%s[%d], edge_lo_%s[%d][%d])' % (
             row, C + j, src.ident, slot(src, u, back), -j - 1)
@@ -403,8 +407,9 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
                       '(%s)0;' % (inst.ident, s, c, c, c, c,
                                   builtin_type(inst.c_type)))
           emit_line('        }')
-          for k in range(inst.edges):
-            for side, ex in (('lo', 'xs - %d' % (k + 1)), ('hi', 'xs + %d' % (LANES * C + k))):
+          for side, k in [('lo', k) for k in range(inst.edges['lo'])] + \
+              [('hi', k) for k in range(inst.edges['hi'])]:
+            for ex in ('xs - %d' % (k + 1) if side == 'lo' else 'xs + %d' % (LANES * C + k),):
               emit_line('        { i64 ex = %s;' % ex)
               emit_line('          if (INTERIOR) { if (ex < 0) ex = 0; if (ex > W - 1) ex = W - 1; '
                         'edge_%s_%s[%d][%d] = g_%s[row * W + ex]; }' % (
@@ -430,9 +435,9 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
           target = ('out_row[%d]' % c) if inst.final else \
               '%s[%d][%d]' % (inst.ident, slot(inst, u, 0), c)
           cell_assignment(stage, target, load, emit_line, '      ')
-        for side in ('lo', 'hi') if inst.edges else ():
+        for side in ('lo', 'hi'):
           # the same row beyond the strip, from the sources' edge columns
-          for c in range(inst.edges):
+          for c in range(inst.edges[side]):
             def load_edge(tensor, rel, u=u, c=c, inst=inst, by_name=by_name, side=side):
               src = by_name[(tensor, tuple(rel))]
               back = inst.lag - src.lag - rel[1]
