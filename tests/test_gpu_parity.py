@@ -1293,6 +1293,37 @@ def test_bench_py_as_the_driver_launches_it_for_two_gpus():
   assert c['super_step_schedule']
 
 
+def test_bench_py_one_rank_group_over_real_rccl():
+  """The N > 1 code path of bench.py with torch's `nccl` backend (= RCCL) for real, as far
+  as one GPU allows: a one-rank process group (`--force-dist`) - RCCL initialisation
+  with a device id, the barrier and the MAX all-reduce on device tensors that bracket the
+  timed region, the slab plan with no neighbours, the JSON line.  What it cannot cover is
+  a send / receive pair between two devices (the gloo rehearsal above and the RCCL
+  stand-in cover their ordering and contents)."""
+  import subprocess
+  import sys
+  from conftest import ROOT
+  r = subprocess.run(
+      [sys.executable, os.path.join(ROOT, 'bench.py'), '--force-dist', '--steps', '2',
+       '--warmup', '1', '--size', '4096', '2000', '--iterate', '60', '--cpu-seconds', '0'],
+      capture_output=True, text=True, timeout=600,
+      env={k: v for k, v in os.environ.items()
+           if k not in ('SODA_DIST_BACKEND', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+  assert len(lines) == 1, r.stdout[-2000:]
+  d = json.loads(lines[0])
+  c = d['config']
+  assert d['n_gpus'] == 1 and c['parallelism'] == 'outer-dim slabs x1'
+  assert c['ghost_rows'] == [c['exchange_every'], c['exchange_every']]
+  assert c['exchange_choice'] == 'given' and c['exchange_candidates_ms'] == []
+  assert 0 < c['compute_only_ms_per_step'] < 1.25 * d['ms_per_step']
+  spec = gpu_util.load_spec('jacobi2d', iterate=60)
+  from soda_hip.codegen import spec as specmod
+  valid = specmod.valid_cells(spec, [4096, 2000], 60)
+  assert abs(d['value'] - valid / (d['ms_per_step'] * 1e-3) / 1e9) < 1e-6 * d['value']
+
+
 def test_denormals_signed_zeros_and_infinities():
   """IEEE corner cases: subnormal inputs (no flush-to-zero on either side),
   negative zeros, infinities (inf - inf = NaN must appear in the same cells)."""
