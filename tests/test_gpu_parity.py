@@ -442,7 +442,8 @@ def test_full_size_cfg4_jacobi2d_16384_x1000():
   1000-iteration dependency cone; and the default schedule (the packed
   wave-pipelined depth-24 / depth-20 kernels fed through the LDS ring, whichever
   split of 1000 the scheduler prices cheapest) agrees with the depth-16 and the
-  depth-8 ones everywhere."""
+  depth-8 ones everywhere; and the result does not depend on where the grid lies
+  (the same input shifted by an odd number of rows and columns: every cell equal)."""
   prog = program('jacobi2d')
   n, it = 16384, 1000
   a = np.random.default_rng(6).random((n, n), dtype=np.float32)
@@ -461,6 +462,14 @@ def test_full_size_cfg4_jacobi2d_16384_x1000():
     assert np.array_equal(deep[0], other), limit
   prog.set_max_depth(0)
   assert deep[0][it:-it, it:-it].std() > 0
+  # translation: the same input cut 91 rows and 37 columns in (no strip, chunk or
+  # 64-byte piece lines up with the first run's) gives the same cells, every one of them
+  del other
+  dy, dx = 91, 37
+  moved = prog.run_numpy([np.ascontiguousarray(a[dy:, dx:])], iterate=it)[0]
+  assert moved.shape == (n - dy, n - dx)
+  assert np.array_equal(moved[it:n - dy - it, it:n - dx - it],
+                        deep[0][dy + it:n - it, dx + it:n - it])
 
 
 def test_full_size_cfg5_jacobi3d_512_x200_and_cfg3_blur_16384():
