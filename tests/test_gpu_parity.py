@@ -262,9 +262,9 @@ def test_3d_wave_pipelined_depth_4(app, shape, iterate):
   assert timing['max_depth'] == 4, timing
 
 
-@pytest.mark.parametrize('options', [dict(), dict(wp_prefetch=1), dict(wp_pairs=0),
-                                     dict(wp_pairs=1, wp_waves_per_eu=3)] + (
-    [dict(wp_loader=1, wp_waves_per_eu=3), dict(wp_split=1), dict(wp_pairs=1, wp_rows=12)]
+@pytest.mark.parametrize('options', [dict(), dict(wp_pairs=0)] + (
+    [dict(wp_prefetch=1), dict(wp_pairs=1, wp_waves_per_eu=3),
+     dict(wp_loader=1, wp_waves_per_eu=3), dict(wp_split=1), dict(wp_pairs=1, wp_rows=12)]
     if os.environ.get('SODA_TEST_ALL_FORMS') else []))
 def test_3d_wave_pipelined_forms_on_heat3d(options):
   """The depth-4 generator on heat3d (FMA-sensitive expression) in its optional
@@ -410,8 +410,7 @@ def test_full_size_properties_jacobi2d_8192():
   (a) a linear ramp is a fixed point of the averaging stencil up to rounding:
       the reference's own test input, checked with the reference's comparator;
   (b) depth-16 blocking and depth-1 launches agree bit for bit;
-  (c) a horizontal band of rows checked against the oracle run on a sub-grid
-      that contains the band's whole dependency cone."""
+  (c) the oracle on the whole grid: every cell of the valid box."""
   prog = program('jacobi2d')
   n, it = 8192, 100
   rng = np.random.default_rng(5)
@@ -423,10 +422,12 @@ def test_full_size_properties_jacobi2d_8192():
   prog.set_max_depth(0)
   assert np.array_equal(deep, flat)
   assert deep[it:-it, it:-it].std() > 0
-  # (c) rows [4000, 4016) depend on input rows [3900, 4116)
-  sub = np.ascontiguousarray(a[3900:4116, :])
-  want = oracle('jacobi2d').run([sub], iterate=it)['t0']
-  assert np.array_equal(deep[4000:4016, it:-it], want[100:116, it:-it])
+  # (c) every cell of the valid box against the oracle
+  want = oracle('jacobi2d').run([a], iterate=it)['t0']
+  sl = oracle('jacobi2d').valid_slices((n, n), it)
+  assert want[sl].shape == (n - 2 * it, n - 2 * it)
+  assert np.array_equal(deep[sl], want[sl])
+  del want
   # (a)
   ramp = host.reference_init(prog.spec, [n, n])
   out = prog.run_numpy(ramp, iterate=it)[0]
@@ -436,13 +437,13 @@ def test_full_size_properties_jacobi2d_8192():
 
 
 def test_full_size_cfg4_jacobi2d_16384_x1000():
-  """BASELINE config 4, the headline workload, at full size: two windows of the
-  result (one in the middle, one in the corner of the valid region) are compared
-  bit for bit with the oracle run on the sub-grid that holds their whole
-  1000-iteration dependency cone; and the default schedule (the packed
-  wave-pipelined depth-24 / depth-20 kernels fed through the LDS ring, whichever
-  split of 1000 the scheduler prices cheapest) agrees with the depth-16 and the
-  depth-8 ones everywhere; and the result does not depend on where the grid lies
+  """BASELINE config 4, the headline workload, at full size against the oracle, EVERY
+  cell of the valid box (the OpenMP oracle at the box's CPU quota takes ~20 s for the
+  2.7e11 updates; conftest sets the team size - at 256 threads on 16 CPUs it took
+  ten times that, which is why rounds 1-3 compared windows only); the default schedule
+  (the packed wave-pipelined depth-24 / depth-20 kernels fed through the LDS ring,
+  whichever split of 1000 the scheduler prices cheapest) agrees with the depth-16 and
+  the depth-8 ones everywhere; and the result does not depend on where the grid lies
   (the same input shifted by an odd number of rows and columns: every cell equal)."""
   prog = program('jacobi2d')
   n, it = 16384, 1000
@@ -450,18 +451,16 @@ def test_full_size_cfg4_jacobi2d_16384_x1000():
   prog.set_max_depth(0)
   deep, timing = prog.run_numpy([a], iterate=it, timed=True)
   assert timing['max_depth'] >= 20
-  for y0, x0 in ((8000, 8000), (it, it), (n - it - 16, n - it - 300)):
-    ys, xs = slice(y0 - it, y0 + 16 + it), slice(x0 - it, x0 + 300 + it)
-    sub = np.ascontiguousarray(a[ys, xs])
-    want = oracle('jacobi2d').run([sub], iterate=it)['t0']
-    assert np.array_equal(deep[0][y0:y0 + 16, x0:x0 + 300],
-                          want[it:it + 16, it:it + 300]), (y0, x0)
+  want = oracle('jacobi2d').run([a], iterate=it)['t0']
+  sl = oracle('jacobi2d').valid_slices((n, n), it)
+  assert want[sl].shape == (n - 2 * it, n - 2 * it) and want[sl].std() > 0
+  assert np.array_equal(deep[0][sl], want[sl])
+  del want
   for limit in (16, 8):
     prog.set_max_depth(limit)
     other = prog.run_numpy([a], iterate=it)[0]
     assert np.array_equal(deep[0], other), limit
   prog.set_max_depth(0)
-  assert deep[0][it:-it, it:-it].std() > 0
   # translation: the same input cut 91 rows and 37 columns in (no strip, chunk or
   # 64-byte piece lines up with the first run's) gives the same cells, every one of them
   del other
