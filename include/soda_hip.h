@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SODA_HIP_ABI_VERSION 5
+#define SODA_HIP_ABI_VERSION 6
 #define SODA_HIP_MAX_DIMS 4
 #define SODA_HIP_MAX_TENSORS 16 /* inputs + stages of one program */
 #define SODA_HIP_MAX_IO 8
@@ -199,6 +199,18 @@ typedef struct soda_hip_kernel {
                          step_ns_*, above fade_hi the kernel streams.  Part of the
                          kernel's calibration record (tools/calibrate.py); 0, 0 = the
                          defaults 128 and 512 */
+  /* (ABI 6) */
+  int32_t stream_chunk; /* N > 0: a launch whose box does not fit the Infinity Cache walks
+                         chunks of N rows (planes) per workgroup instead of the longest
+                         chunk that fills the chip in whole rounds.  Measured per kernel
+                         (tools/calibrate.py: the fastest of a few chunk lengths and caps on
+                         a streaming array; stream_wgs_per_cu and stream_gbps then belong
+                         to THIS chunk): the memory-bound kernels move up to 15 % more
+                         bytes per second when many short-lived workgroups, dispatched in
+                         address order, keep the rows the chip works on close together
+                         (jacobi2d 16384^2 depth 1: 436 -> 378 us with 16 rows, blur 226
+                         -> 200, sobel2d 246 -> 212; profiles/r04_stream_chunk.txt).
+                         0 = the launcher's own choice */
 } soda_hip_kernel;
 
 /* By-value argument of every generated kernel. */

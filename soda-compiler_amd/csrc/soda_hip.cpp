@@ -393,6 +393,12 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
           best = chunk;
         }
       }
+      // the kernel's measured chunk for boxes beyond the cache (soda_hip_kernel.
+      // stream_chunk): short chunks in dispatch order keep the rows in flight together
+      // (tuning: SODA_HIP_CHUNK_ROWS = N forces N, -1 the rule above whatever the kernel says)
+      if (desc.stream_chunk > 0 && footprint > kBeyondCacheBytes &&
+          plan->chunk_rows_override == 0)
+        best = std::max<int64_t>(1, std::min<int64_t>(desc.stream_chunk, extent));
       if (plan->chunk_rows_override > 0) best = plan->chunk_rows_override;
       tile = best;
       out->args.param[0] = best;
@@ -1348,12 +1354,13 @@ int soda_hip_sweep_timed(soda_hip_plan* plan, void* const* in, void* const* out,
       for (size_t i = 0; i < list.size(); ++i) {
         const soda_hip_args& a = list[i].args;
         fprintf(stderr, "soda_hip: launch %3zu %-28s %8.1f us (model %7.1f)  box %lld x %lld x %lld  "
-                "grid %u x %u x %u  chunk %lld  fill %d  resident %d\n", i,
+                "grid %u x %u x %u  chunk %lld  fill %d  resident %d  lds %u\n", i,
                 plan->kernels[list[i].kernel].name,
                 fastest[i] * 1000.0, list[i].est_us, (long long)(a.box_hi[0] - a.box_lo[0]),
                 (long long)(a.box_hi[1] - a.box_lo[1]), (long long)(a.box_hi[2] - a.box_lo[2]),
                 list[i].grid[0], list[i].grid[1], list[i].grid[2], (long long)a.param[0],
-                plan->kernels[list[i].kernel].fill_rows, plan->resident_blocks[list[i].kernel]);
+                plan->kernels[list[i].kernel].fill_rows, plan->resident_blocks[list[i].kernel],
+                list[i].lds_bytes);
       }
     timing->kernel_us = total_ms * 1000.0 / repeats;
     timing->fastest_us = fastest_ms * 1000.0;

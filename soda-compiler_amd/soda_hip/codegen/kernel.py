@@ -248,7 +248,10 @@ WP_STEP_FIXED_CYCLES = 640
 CALIBRATION_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)),
                                 'calibration.json')
 CALIBRATED_FIELDS = ('step_ns_full', 'step_ns_one', 'stream_gbps', 'fade_lo_mib',
-                     'fade_hi_mib')
+                     'fade_hi_mib', 'stream_chunk')
+# ... and one the generator sets a default for, which a measurement may replace (the cap
+# on workgroups per CU that goes with the measured chunk)
+MEASURED_OVER_DEFAULT = ('stream_wgs_per_cu',)
 _calibration = None
 
 
@@ -261,7 +264,7 @@ def calibration_key(entry, spec):
   import hashlib
   import json
   shape = {k: v for k, v in entry.items()
-           if k not in CALIBRATED_FIELDS + ('step_valu', 'step_bytes')}
+           if k not in CALIBRATED_FIELDS + MEASURED_OVER_DEFAULT + ('step_valu', 'step_bytes')}
   digest = hashlib.sha1(json.dumps(shape, sort_keys=True).encode()).hexdigest()[:12]
   return '%s/%s/%s' % (kernel_common.program_hash(spec)[:12], entry['name'], digest)
 
@@ -314,6 +317,9 @@ def annotate_cost(entry, spec):
   if measured:
     for field in CALIBRATED_FIELDS:
       entry[field] = int(measured.get(field, 0))
+    for field in MEASURED_OVER_DEFAULT:
+      if field in measured:
+        entry[field] = int(measured[field])
   return entry
 
 

@@ -12,7 +12,7 @@ import re
 
 from . import spec as specmod
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # A launch whose box (inputs + outputs) is larger than this streams: nothing it writes
 # is still cached when the next launch reads it, and its stores go out non-temporal

@@ -11,7 +11,7 @@ MAX_TENSORS = 16
 MAX_IO = 8
 MAX_WINDOWS = 64
 MAX_KERNELS = 32
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 KERNEL_STAGE = 0
 KERNEL_FUSED = 1
@@ -48,7 +48,8 @@ class KernelDesc(ctypes.Structure):
               ('stream_gbps', ctypes.c_int32),
               ('xcd_tiles', ctypes.c_int32),
               ('stream_wgs_per_cu', ctypes.c_int32),
-              ('fade_lo_mib', ctypes.c_int32), ('fade_hi_mib', ctypes.c_int32)]
+              ('fade_lo_mib', ctypes.c_int32), ('fade_hi_mib', ctypes.c_int32),
+              ('stream_chunk', ctypes.c_int32)]
 
 
 class Slab(ctypes.Structure):

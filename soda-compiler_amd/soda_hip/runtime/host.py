@@ -193,6 +193,7 @@ def kernel_descs(table):
     d.stream_wgs_per_cu = int(k.get('stream_wgs_per_cu', 0))
     d.fade_lo_mib = int(k.get('fade_lo_mib', 0))
     d.fade_hi_mib = int(k.get('fade_hi_mib', 0))
+    d.stream_chunk = int(k.get('stream_chunk', 0))
   return arr
 
 

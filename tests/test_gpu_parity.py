@@ -1466,11 +1466,14 @@ def test_run_on_data_in_the_reference_dram_layout(fixture):
   prog.blob.unload()
 
 
-def test_streaming_launches_of_the_depth1_kernel_are_capped_per_cu():
-  """soda_hip_kernel.stream_wgs_per_cu (ABI 5): a launch of the seam-free depth-1 kernel
-  whose box does not fit the Infinity Cache runs at most two workgroups per CU - fewer
-  workgroups on longer chunks - while a cache-resident one fills the chip; results are the
-  same either way (the cap only changes the chunk length)."""
+def test_streaming_launches_of_the_depth1_kernel_use_the_measured_chunk_and_cap():
+  """soda_hip_kernel.stream_chunk (ABI 6) and stream_wgs_per_cu (ABI 5): a launch of the
+  depth-1 kernel whose box does not fit the Infinity Cache walks the chunk length that
+  tools/calibrate.py measured as the fastest for it (short chunks, many workgroups
+  dispatched in address order) under the measured cap on workgroups per CU, while a
+  cache-resident launch keeps the launcher's own rule (the longest chunk that fills the
+  chip in whole rounds, no cap); results are the same either way (chunk and cap decide
+  where rows are computed, not what)."""
   import re
   import subprocess
   import sys
@@ -1493,11 +1496,21 @@ def test_streaming_launches_of_the_depth1_kernel_are_capped_per_cu():
                      timeout=300)
   assert r.returncode == 0, r.stderr[-2000:]
   launches = re.findall(r'launch\s+\d+ jacobi2d_fused_k1\s+[\d.]+ us \(model\s+[\d.]+\)  box (\d+) x '
-                        r'(\d+) x \d+  grid (\d+) x (\d+) x \d+  chunk (\d+)', r.stderr)
+                        r'(\d+) x \d+  grid (\d+) x (\d+) x \d+  chunk (\d+)  fill \d+  '
+                        r'resident \d+  lds (\d+)', r.stderr)
   assert len(launches) == 2, r.stderr[-2000:]
   entry = [k for k in program('jacobi2d').kernels if k['name'] == 'jacobi2d_fused_k1'][0]
-  assert entry['stream_wgs_per_cu'] == 2 and entry['exact'] == 1
+  assert entry['exact'] == 1
   cus = host.device_info(0)['compute_units']
-  small, big = [(int(gx) * int(gy), int(chunk)) for _, _, gx, gy, chunk in launches]
-  assert small[0] > 2 * cus          # 3072^2 (72 MiB in + out): the chip is filled
-  assert big[0] <= 2 * cus and big[1] > 4 * small[1]      # 12288^2: <= 2 per CU, long chunks
+  small, big = [(int(gx) * int(gy), int(chunk), int(lds))
+                for _, _, gx, gy, chunk, lds in launches]
+  assert small[0] > 2 * cus and small[2] == 0          # 3072^2 (72 MiB): the chip is filled
+  if entry.get('stream_chunk', 0) > 0:      # 12288^2: the measured chunk, many workgroups
+    assert big[1] == entry['stream_chunk'] and big[0] > 8 * cus
+  else:
+    assert big[1] > 4 * small[1]
+  if entry.get('stream_wgs_per_cu', 0) > 0:     # the cap: dynamic LDS nobody touches
+    cap = entry['stream_wgs_per_cu']
+    assert 160 * 1024 // (cap + 1) < big[2] <= 160 * 1024 // cap
+  else:
+    assert big[2] == 0

@@ -14,6 +14,10 @@ that deep kernel:
   * an array in between (about twice the cache) -> fade_lo_mib / fade_hi_mib: the
     footprints between which the HBM term of the price fades in (soda_hip.cpp:
     step_seconds), placed so that the model reproduces this launch
+  * shallow kernels (the ones HBM bounds): the streaming launch again under a few chunk
+    lengths and caps on workgroups per CU -> stream_chunk (+ stream_wgs_per_cu) when one
+    of them beats the launcher's own chunk by 3 % or more; stream_gbps is then the rate
+    of THAT launch
 step = launch time / (rounds x (chunk + fill rows)), from the library's own launch
 trace (SODA_HIP_LAUNCH_TRACE).
 
@@ -30,6 +34,9 @@ SIZES = {   # (cache-resident, streaming, in between) extents per dimension
     3: (256, 512, 384),
 }
 FADE_DEFAULT = (128, 512)      # MiB; soda_hip.cpp: kCacheResidentMiB, kStreamingMiB
+# chunk lengths tried for the streaming launch of kernels up to this depth
+STREAM_CHUNKS = (8, 12, 16, 24, 32, 48, 64, 96)
+STREAM_SWEEP_MAX_DEPTH = {2: 4, 3: 2}
 
 
 def fade_footprints(spec, mid_extent, cached_ns, mid_ns, stream_ns):
@@ -100,10 +107,87 @@ def child(app, depth, form, n, chunk, name=None):
   prog.close()
 
 
+def parse_launch(fields):
+  name, us, bx, by, bz, gx, gy, gz, chunk_used, fill, resident = fields
+  blocks = int(gx) * int(gy) * int(gz)
+  rounds = -(-blocks // int(resident))
+  steps = rounds * (int(chunk_used) + int(fill))
+  return dict(name=name, us=float(us), blocks=blocks, resident=int(resident), steps=steps,
+              chunk=int(chunk_used),
+              # (the scheduler adds 2 us per launch on top of the steps)
+              step_ns=max(1.0, float(us) - 2.0) * 1e3 / steps)
+
+
+def child_sweep(app, depth, form, n, name, settings):
+  """One compile, then the streaming launch under every (chunk, cap) of `settings`
+  ('chunk:cap,...'; cap '' = the kernel's own, -1 = none): a marker line and the
+  library's launch trace per setting on stderr."""
+  sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd')]
+  import numpy as np
+  from soda_hip import frontend
+  from soda_hip.codegen import kernel, spec as specmod
+  from soda_hip.runtime import host
+  import __graft_entry__ as entry
+  st = frontend.load(entry.sample_path(app), iterate=entry.BLOB_ITERATE.get(app))
+  spec = specmod.spec_from_stencil(st)
+  opts = dict(depths=[depth])
+  if form:
+    opts['deep3d'] = form
+  text, table = kernel.generate(spec, **opts)
+  path = '/tmp/calib_%d.hsaco' % os.getpid()
+  kernel.compile_to_code_object(text, path)
+  dims = [n] * spec['dim']
+  shape = tuple(reversed(dims))
+  dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
+  rng = np.random.default_rng(1)
+  a = rng.random(shape, dtype=np.float32).astype(dt) if dt.kind == 'f' else \
+      rng.integers(0, 65536, size=shape).astype(dt)
+  din = host.DeviceArray(a.nbytes)
+  din.upload(a)
+  dout = host.DeviceArray(a.nbytes)
+  dout.zero()
+  os.environ['SODA_HIP_PREFER'] = name[name.index('_fused_'):]
+  for setting in settings.split(','):
+    chunk, cap = setting.split(':')
+    os.environ['SODA_HIP_CHUNK_ROWS'] = chunk
+    os.environ.pop('SODA_HIP_WGS_PER_CU', None)
+    if cap:
+      os.environ['SODA_HIP_WGS_PER_CU'] = cap
+    prog = host.open_program(blob=path, spec=spec)
+    os.environ.pop('SODA_HIP_LAUNCH_TRACE', None)
+    probe = prog.sweep_timed([din.ptr], [dout.ptr], dims, depth, warmup=1, repeats=1)
+    warm = int(min(500, max(3, 40000.0 / max(1.0, probe['kernel_us']))))
+    sys.stderr.write('SETTING %s\n' % setting)
+    sys.stderr.flush()
+    os.environ['SODA_HIP_LAUNCH_TRACE'] = '1'
+    prog.sweep_timed([din.ptr], [dout.ptr], dims, depth, warmup=warm, repeats=5)
+    prog.close()
+
+
+def measure_sweep(app, depth, form, n, name, settings):
+  """{(chunk, cap): launch record} of the streaming launch under each setting."""
+  env = dict(os.environ, SODA_HIP_TUNING='1')
+  p = subprocess.run([sys.executable, __file__, '--sweep', app, str(depth), form or '-',
+                      str(n), name, ','.join('%d:%s' % s for s in settings)], env=env,
+                     capture_output=True, text=True)
+  out = {}
+  current = None
+  for line in p.stderr.splitlines():
+    if line.startswith('SETTING '):
+      chunk, cap = line.split()[1].split(':')
+      current = (int(chunk), cap)
+    else:
+      m = TRACE.search(line)
+      if m and current is not None and m.group(1) == name:
+        out[current] = parse_launch(m.groups())
+        current = None
+  return out
+
+
 def measure(app, depth, form, n, chunk=0, name=None):
   env = dict(os.environ, SODA_HIP_TUNING='1', SODA_HIP_LAUNCH_TRACE='1')
-  if chunk:
-    env['SODA_HIP_CHUNK_ROWS'] = str(chunk)
+  # (-1: the launcher's own chunk, whatever an earlier calibration says)
+  env['SODA_HIP_CHUNK_ROWS'] = str(chunk if chunk else -1)
   if name:      # several kernels of this depth in the blob: this one, whatever its price
     env['SODA_HIP_PREFER'] = name[name.index('_fused_'):]
   p = subprocess.run([sys.executable, __file__, '--child', app, str(depth), form or '-',
@@ -114,14 +198,7 @@ def measure(app, depth, form, n, chunk=0, name=None):
   if not m or not launches:
     return None
   info = json.loads(m.group(1))
-  name, us, bx, by, bz, gx, gy, gz, chunk_used, fill, resident = launches[0]
-  blocks = int(gx) * int(gy) * int(gz)
-  rounds = -(-blocks // int(resident))
-  steps = rounds * (int(chunk_used) + int(fill))
-  return dict(info, name=name, us=float(us), blocks=blocks, resident=int(resident),
-              steps=steps, chunk=int(chunk_used),
-              # (the scheduler adds 2 us per launch on top of the steps)
-              step_ns=max(1.0, float(us) - 2.0) * 1e3 / steps)
+  return dict(info, **parse_launch(launches[0]))
 
 
 def main():
@@ -162,6 +239,22 @@ def main():
       if not one or not stream or not mid:
         print('%-28s partly measured' % k['name'])
         continue
+      chosen = None
+      if k['depth'] <= STREAM_SWEEP_MAX_DEPTH.get(dim, 0):
+        own_cap = int(k.get('stream_wgs_per_cu', 0))
+        caps = ['', '2'] if own_cap != 2 else ['', '-1']
+        settings = [(c, cap) for cap in caps for c in STREAM_CHUNKS]
+        sweep = measure_sweep(app, k['depth'], form, big, k['name'], settings)
+        if sweep:
+          (c, cap), rec = min(sweep.items(), key=lambda kv: kv[1]['us'])
+          print('%-28s streaming launch: own chunk %d %.1f us; best of %d settings: chunk %d '
+                'cap %s %.1f us' % (k['name'], stream['chunk'], stream['us'], len(sweep), c,
+                                    cap or 'own', rec['us']), flush=True)
+          if rec['us'] < 0.97 * stream['us']:
+            chosen = dict(stream_chunk=c)
+            if cap:
+              chosen['stream_wgs_per_cu'] = max(0, int(cap))
+            stream = dict(stream, **rec)
       active = min(stream['blocks'], stream['resident'])
       gbps = active * k['step_bytes'] / stream['step_ns']      # bytes / ns = GB/s
       # the step on the in-between array, at the occupancy it ran at, against the cached
@@ -174,7 +267,7 @@ def main():
       table['kernels'][full['key']] = dict(
           name=k['name'], app=app, step_ns_full=int(round(full['step_ns'])),
           step_ns_one=int(round(one['step_ns'])), stream_gbps=int(round(gbps)),
-          fade_lo_mib=fade_lo, fade_hi_mib=fade_hi,
+          fade_lo_mib=fade_lo, fade_hi_mib=fade_hi, **(chosen or {}),
           measured=dict(full=[small, full['blocks'], full['steps'], full['us']],
                         one=[small, one['blocks'], one['steps'], one['us']],
                         stream=[big, stream['blocks'], stream['steps'], stream['us']],
@@ -205,5 +298,8 @@ if __name__ == '__main__':
     child(sys.argv[2], int(sys.argv[3]), None if sys.argv[4] == '-' else sys.argv[4],
           int(sys.argv[5]), int(sys.argv[6]),
           None if len(sys.argv) < 8 or sys.argv[7] == '-' else sys.argv[7])
+  elif len(sys.argv) > 1 and sys.argv[1] == '--sweep':
+    child_sweep(sys.argv[2], int(sys.argv[3]), None if sys.argv[4] == '-' else sys.argv[4],
+                int(sys.argv[5]), sys.argv[6], sys.argv[7])
   else:
     main()
