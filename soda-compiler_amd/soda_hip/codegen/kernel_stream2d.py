@@ -351,6 +351,11 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
   emit_line('  // load head: first input row the chunk depends on')
   emit_line('  i64 head = y0 - %d;' % geo['y_lo'])
   emit_line('  const i64 steps = (y1 - y0) + %d;' % (L + geo['y_lo']))
+  # the last input row any stored row depends on: the rows streamed after it only flush
+  # the pipeline, and outside the branch-free loop they are not loaded (with the short
+  # chunks of streaming launches - soda_hip_kernel.stream_chunk - they would be a
+  # quarter of all row loads)
+  emit_line('  const i64 load_last = y1 - 1 + %d;' % geo['y_hi'])
   prologue_steps = max(i.first_step for i in insts)
   prologue_steps = -(-prologue_steps // period) * period if skip_fill else 0
   emit_line('  i64 n = 0;')
@@ -386,7 +391,12 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, max_period=12,
       for inst in insts:
         if inst.stage is None:
           s = slot(inst, u, 0)
-          emit_line('      {  // load row head+%d of %s' % (u, inst.tensor))
+          # (only where the row loop proper is the branch-free copy: a branch around the
+          # loads of the ONE loop of a deeper kernel makes the compiler wait for every
+          # load in flight at its join - blur depth 4 298 -> 404 us per launch)
+          emit_line('      %s{  // load row head+%d of %s' % (
+              'if (head + %d <= load_last) ' % u if steady and not calm else '', u,
+              inst.tensor))
           emit_line('        i64 row = head + %d;%s' % (
               u, '' if calm else ' if (row > H - 1) row = H - 1;'))
           emit_line('        const %s* p = g_%s + row * W + x;' % (

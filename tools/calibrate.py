@@ -251,9 +251,10 @@ def main():
                 'cap %s %.1f us' % (k['name'], stream['chunk'], stream['us'], len(sweep), c,
                                     cap or 'own', rec['us']), flush=True)
           if rec['us'] < 0.97 * stream['us']:
-            chosen = dict(stream_chunk=c)
-            if cap:
-              chosen['stream_wgs_per_cu'] = max(0, int(cap))
+            # (the cap in effect, spelled out: "the kernel's own" may itself come from
+            # an earlier calibration, which this record replaces)
+            chosen = dict(stream_chunk=c,
+                          stream_wgs_per_cu=own_cap if not cap else max(0, int(cap)))
             stream = dict(stream, **rec)
       active = min(stream['blocks'], stream['resident'])
       gbps = active * k['step_bytes'] / stream['step_ns']      # bytes / ns = GB/s
