@@ -244,6 +244,8 @@ struct Launch {
   unsigned grid[3];
   double est_us;   // modelled duration (0 = the kernel carries no cost figures)
   unsigned lds_bytes = 0;   // dynamic LDS asked for only to cap the workgroups per CU
+  long long rounds = 0;     // streaming kernels: chip-fulls of workgroups the price assumes
+  long long resident = 0;   // ... and the workgroups one chip-full is (after any cap)
 };
 
 // Cost model of a streaming launch (what the scheduler compares depths with; it
@@ -279,12 +281,16 @@ const double kStreamingMiB = 512.0;
 // non-temporal paths switch at the same figure: kernel_common.NT_STREAMING_BYTES)
 const double kBeyondCacheBytes = 288.0 * 1024 * 1024;
 
-double step_seconds(const soda_hip_plan* plan, int k, double blocks, double footprint = 0) {
+// `resident` = workgroups of this launch the chip holds at once (the kernel's occupancy,
+// or less under a cap on workgroups per CU; 0 = the kernel's occupancy)
+double step_seconds(const soda_hip_plan* plan, int k, double blocks, double footprint = 0,
+                    double resident = 0) {
   const soda_hip_kernel& desc = plan->kernels[k];
   const double cus = std::max(1, plan->cus);
   const double full = std::max(1, plan->resident_blocks[k]) / cus;
+  const double held = resident > 0 ? std::min(full, resident / cus) : full;
   // a grid smaller than the chip holds: fewer workgroups share each CU
-  const double per_cu = std::min(full, std::max(1.0, blocks / cus));
+  const double per_cu = std::min(held, std::max(1.0, blocks / cus));
   if (desc.step_ns_full > 0 && desc.step_ns_one > 0) {
     const double share = full > 1 ? (per_cu - 1) / (full - 1) : 1.0;
     double t = (desc.step_ns_one + (desc.step_ns_full - desc.step_ns_one) * share) * 1e-9;
@@ -294,7 +300,7 @@ double step_seconds(const soda_hip_plan* plan, int k, double blocks, double foot
         (desc.fade_hi_mib > 0 ? desc.fade_hi_mib : kStreamingMiB) * mib);
     if (desc.stream_gbps > 0 && desc.step_bytes > 0 && footprint > fade_lo) {
       const double weight = std::min(1.0, (footprint - fade_lo) / (fade_hi - fade_lo));
-      t = std::max(t, weight * std::min(blocks, full * cus) * desc.step_bytes /
+      t = std::max(t, weight * std::min(blocks, held * cus) * desc.step_bytes /
                           (desc.stream_gbps * 1e9));
     }
     return t;
@@ -404,8 +410,11 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
       out->args.param[0] = best;
       const double blocks = (double)inner * (double)((extent + best - 1) / best);
       const double rounds = std::ceil(blocks / (double)resident);
+      out->rounds = (long long)rounds;
       out->est_us = kModelLaunchUs + rounds * (double)(best + desc.fill_rows) *
-                                         step_seconds(plan, k, blocks, footprint) * 1e6;
+                                         step_seconds(plan, k, blocks, footprint,
+                                                      (double)resident) * 1e6;
+      out->resident = (long long)resident;
     }
     int64_t g = (extent + tile - 1) / tile;
     if (d > 0 && desc.kind == SODA_HIP_KERNEL_STAGE && (g > 65535 || dim > 3)) {
@@ -1354,13 +1363,15 @@ int soda_hip_sweep_timed(soda_hip_plan* plan, void* const* in, void* const* out,
       for (size_t i = 0; i < list.size(); ++i) {
         const soda_hip_args& a = list[i].args;
         fprintf(stderr, "soda_hip: launch %3zu %-28s %8.1f us (model %7.1f)  box %lld x %lld x %lld  "
-                "grid %u x %u x %u  chunk %lld  fill %d  resident %d  lds %u\n", i,
+                "grid %u x %u x %u  chunk %lld  fill %d  resident %d  lds %u  rounds %lld\n", i,
                 plan->kernels[list[i].kernel].name,
                 fastest[i] * 1000.0, list[i].est_us, (long long)(a.box_hi[0] - a.box_lo[0]),
                 (long long)(a.box_hi[1] - a.box_lo[1]), (long long)(a.box_hi[2] - a.box_lo[2]),
                 list[i].grid[0], list[i].grid[1], list[i].grid[2], (long long)a.param[0],
-                plan->kernels[list[i].kernel].fill_rows, plan->resident_blocks[list[i].kernel],
-                list[i].lds_bytes);
+                plan->kernels[list[i].kernel].fill_rows,
+                list[i].resident > 0 ? (int)list[i].resident
+                                     : plan->resident_blocks[list[i].kernel],
+                list[i].lds_bytes, list[i].rounds);
       }
     timing->kernel_us = total_ms * 1000.0 / repeats;
     timing->fastest_us = fastest_ms * 1000.0;

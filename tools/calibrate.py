@@ -59,7 +59,8 @@ def fade_footprints(spec, mid_extent, cached_ns, mid_ns, stream_ns):
   return lo, int(min(8192, max(footprint, lo + (footprint - lo) / w)))
 APPS = ['jacobi2d', 'seidel2d', 'blur', 'sobel2d', 'jacobi3d', 'heat3d']
 TRACE = re.compile(r'launch\s+\d+ (\S+)\s+([\d.]+) us \(model\s+[\d.]+\)  box (\d+) x (\d+) x (\d+)  '
-                   r'grid (\d+) x (\d+) x (\d+)  chunk (\d+)  fill (\d+)  resident (\d+)')
+                   r'grid (\d+) x (\d+) x (\d+)  chunk (\d+)  fill (\d+)  resident (\d+)'
+                   r'  lds \d+  rounds (\d+)')
 
 
 def child(app, depth, form, n, chunk, name=None):
@@ -108,9 +109,11 @@ def child(app, depth, form, n, chunk, name=None):
 
 
 def parse_launch(fields):
-  name, us, bx, by, bz, gx, gy, gz, chunk_used, fill, resident = fields
+  name, us, bx, by, bz, gx, gy, gz, chunk_used, fill, resident, rounds = fields
   blocks = int(gx) * int(gy) * int(gz)
-  rounds = -(-blocks // int(resident))
+  # the rounds the LAUNCHER prices (under a cap on workgroups per CU more than blocks /
+  # resident): step_ns and stream_gbps must reproduce this launch through ITS formula
+  rounds = int(rounds)
   steps = rounds * (int(chunk_used) + int(fill))
   return dict(name=name, us=float(us), blocks=blocks, resident=int(resident), steps=steps,
               chunk=int(chunk_used),
