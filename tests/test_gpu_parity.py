@@ -436,6 +436,40 @@ def test_full_size_properties_jacobi2d_8192():
   assert rel.max() < 1e-4
 
 
+@pytest.mark.parametrize('app,n,iterate,max_depth', [
+    ('jacobi2d', 8192, 7, 4),       # 4 + 2 + 1: all three shallow kernels, 512 MiB in + out
+    ('seidel2d', 8192, 3, 2),
+    ('sobel2d', 12288, 1, 0),       # uint16: 576 MiB in + out
+    ('blur', 12288, 3, 2),
+    ('jacobi3d', 448, 3, 2),        # 3-D block kernels of depth 2 and 1: 686 MiB
+])
+def test_streaming_launches_of_the_shallow_kernels_against_the_oracle(app, n, iterate,
+                                                                     max_depth):
+  """Boxes beyond the Infinity Cache take the launch rule of soda_hip_kernel.stream_chunk
+  (short chunks, the measured cap) and, in the depth <= 2 kernels, the row loop that does
+  not load its pipeline-flush rows: every cell of the valid box against the oracle, for
+  every shallow kernel that has such a record."""
+  prog = program(app)
+  spec = prog.spec
+  dims = [n] * spec['dim']
+  rng = np.random.default_rng(n + iterate)
+  dt = prog.in_dtypes[0]
+  shape = tuple(reversed(dims))
+  a = rng.random(shape, dtype=np.float32) if dt.kind == 'f' else \
+      rng.integers(0, 2048, size=shape).astype(dt)
+  prog.set_max_depth(max_depth)
+  try:
+    got, timing = prog.run_numpy([a], iterate=iterate, timed=True)
+  finally:
+    prog.set_max_depth(0)
+  chunked = [k['name'] for k in prog.kernels if k.get('stream_chunk', 0) > 0]
+  assert chunked, 'no kernel of %s carries a measured stream chunk' % app
+  orc = oracle(app)
+  want = orc.run([a], iterate=iterate)[spec['outputs'][0]]
+  sl = orc.valid_slices(tuple(dims), iterate)
+  assert want[sl].size > 0 and np.array_equal(got[0][sl], want[sl])
+
+
 def test_full_size_cfg4_jacobi2d_16384_x1000():
   """BASELINE config 4, the headline workload, at full size against the oracle, EVERY
   cell of the valid box (the OpenMP oracle at the box's CPU quota takes ~20 s for the
