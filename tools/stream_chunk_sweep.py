@@ -16,8 +16,6 @@ caps = [int(v) for v in (sys.argv[5] if len(sys.argv) > 5 else '-1').split(',')]
 spec = gpu_util.load_spec(app, iterate=depth)
 dims = [n] * spec['dim']
 shape = tuple(reversed(dims))
-dt = np.dtype(gpu_util.specmod.NUMPY_NAME[spec['inputs'][0]['c_type']]) \
-    if hasattr(gpu_util, 'specmod') else None
 from soda_hip.codegen import spec as specmod
 dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
 rng = np.random.default_rng(1)
