@@ -77,6 +77,9 @@ def parse_args():
                        'config.depth_schedule of an earlier run prints it (profiling '
                        'passes repeat the schedule of the timed run with it); implies '
                        '--no-tune (soda_hip_plan_set_split)')
+  ap.add_argument('--no-other-configs', action='store_true',
+                  help='N = 1, headline workload: do not time BASELINE configs 2, 3 and 5 '
+                       'after it (config.other_configs)')
   ap.add_argument('--jit', action='store_true',
                   help='compile the kernels with hiprtc instead of loading the '
                        'code object built by __graft_entry__.build()')
@@ -310,6 +313,17 @@ def roofline_block(spec, program, schedule, updates, timing, dims, iterate,
     block.update(valu_issue_utilisation=sq['valu_issue_utilisation'],
                  wave_parked=sq.get('wave_parked'), counters_source=sq_source)
     valu_binds = sq['valu_issue_utilisation'] > hbm_frac / HBM_ACHIEVABLE_FRAC
+    # what separates valu_frac from 1: valu_frac = issue utilisation x useful share of
+    # the issued instructions x shader clock / 2.4 GHz.  Wave-level VALU instructions
+    # and shader cycles per launch are the counters' (GRBM_GUI_ACTIVE / 8 XCDs); a
+    # packed instruction covers 128 lane-operations, a scalar one 64.
+    packed = any(e.get('pairs') for e, _ in schedule if e['name'] == name)
+    if sq.get('valu_instructions'):
+      block['useful_instruction_share'] = upd * ops / (128.0 if packed else 64.0) / \
+          sq['valu_instructions']
+    if sq.get('shader_cycles'):
+      block['shader_cycles_per_launch'] = sq['shader_cycles']
+      block['shader_clock_ghz'] = sq['shader_cycles'] / (avg_s * 1e9)
   if valu_binds:
     block.update(bound='valu', achieved=valu, peak=VALU_PEAK_TLANEOPS,
                  unit='Tlane-op/s', frac=block['valu_frac'])
@@ -345,13 +359,29 @@ def schedule_text(schedule):
   return '+'.join('%dx%s' % (n, label) for label, n in runs)
 
 
-def run_single(args):
+# The other single-GPU BASELINE configs ("plus cfg 2, 3, 5 single-point
+# numbers"): timed after the headline on the same device in the same process, 30 steps
+# after 10 of warm-up each (a burst of a few milliseconds runs at lower clocks), and
+# printed under config.other_configs.
+OTHER_CONFIGS = (
+    ('cfg2', 'jacobi2d', [8192, 8192], 100),
+    ('cfg3', 'blur', [16384, 16384], 1),
+    ('cfg5', 'jacobi3d', [512, 512, 512], 200),
+)
+OTHER_STEPS, OTHER_WARMUP = 30, 10
+
+
+def measure(app, dims, iterate, steps, warmup, max_depth=0, split='', no_tune=False,
+            jit=False):
+  """One workload under the bench protocol on the current device: `warmup` untimed
+  sweeps (+ the tuning step), `steps` timed ones, then the same sweep under per-launch
+  events for the roofline entry.  Returns (result line, spec)."""
   import torch
   from soda_hip.codegen import spec as specmod
   from soda_hip.runtime import host
-  program, spec = open_program(args.app, args.iterate, args.jit)
-  program.set_max_depth(args.max_depth)
-  dims = list(args.size)
+  program, spec = open_program(app, iterate, jit)
+  program.set_max_depth(max_depth)
+  dims = list(dims)
   inputs = make_input(spec, dims)
   cells = int(np.prod(dims))
   din = [host.DeviceArray(a.nbytes) for a in inputs]
@@ -364,59 +394,93 @@ def run_single(args):
   ip, op = [d.ptr for d in din], [d.ptr for d in dout]
   sync = torch.cuda.synchronize if torch.cuda.is_available() else \
       (lambda: host.capi.check(host.capi.lib().soda_hip_stream_synchronize(None)))
-  if args.split:
-    program.set_split(dims, args.iterate, parse_split(args.split, args.iterate))
-    args.no_tune = True
-  for _ in range(args.warmup):
-    program.sweep(ip, op, dims, args.iterate)
+  if split:
+    program.set_split(dims, iterate, parse_split(split, iterate))
+    no_tune = True
+  for _ in range(warmup):
+    program.sweep(ip, op, dims, iterate)
   sync()
-  if not args.no_tune and args.iterate > 1:
-    # untimed, like the warm-up: the candidate splits of `iterate` run as whole
-    # sweeps, the fastest on this device is kept
-    program.tune(ip, op, dims, args.iterate)
-    program.sweep(ip, op, dims, args.iterate)
+  if not no_tune:
+    # untimed, like the warm-up: the candidate splits of `iterate` and the chunk lengths
+    # of the memory-bound launches run as whole sweeps, the fastest on this device is kept
+    program.tune(ip, op, dims, iterate)
+    program.sweep(ip, op, dims, iterate)
     sync()
   t0 = time.perf_counter()
-  for _ in range(args.steps):
-    program.sweep(ip, op, dims, args.iterate)
+  for _ in range(steps):
+    program.sweep(ip, op, dims, iterate)
   sync()
   wall = time.perf_counter() - t0
   # the same loop under hipEvents, per launch, for the roofline entry: three repeats,
   # every launch at its fastest
-  timing = program.sweep_timed(ip, op, dims, args.iterate, warmup=0, repeats=3)
-  schedule = program.schedule(dims, args.iterate)
-  valid = specmod.valid_cells(spec, dims, args.iterate)
-  nominal = cells * args.iterate
-  ms_per_step = wall / args.steps * 1e3
-  value = valid / (wall / args.steps) / 1e9
+  timing = program.sweep_timed(ip, op, dims, iterate, warmup=0, repeats=3)
+  schedule = program.schedule(dims, iterate)
+  valid = specmod.valid_cells(spec, dims, iterate)
+  nominal = cells * iterate
+  ms_per_step = wall / steps * 1e3
+  value = valid / (wall / steps) / 1e9
   abytes = specmod.algorithmic_bytes_per_update(spec)
   result = dict(
       metric='gcell_updates_per_s', value=value, unit='Gcell-updates/s',
-      n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
+      n_gpus=1, steps=steps, warmup=warmup, ms_per_step=ms_per_step,
       higher_is_better=True, scaling='strong', vs_baseline=None,
       dtype='f32' if program.in_dtypes[0].kind == 'f' else 'u%d' % (
           8 * program.in_dtypes[0].itemsize),
       data='synthetic',
       config=dict(workload='%s.soda %s %s, iterate %d' % (
-          args.app, program.in_dtypes[0].name, 'x'.join(map(str, dims)),
-          args.iterate), app=args.app, dims=dims, iterate=args.iterate,
+          app, program.in_dtypes[0].name, 'x'.join(map(str, dims)),
+          iterate), app=app, dims=dims, iterate=iterate,
                   valid_cell_updates=valid, nominal_cell_updates=nominal,
-                  nominal_gcell_updates_per_s=nominal / (wall / args.steps) / 1e9,
+                  nominal_gcell_updates_per_s=nominal / (wall / steps) / 1e9,
                   launches_per_step=timing['launches'],
                   depth_schedule=schedule_text(schedule),
-                  depth_split='given (--split)' if args.split else
-                  'measured (soda_hip_plan_tune)' if not args.no_tune and
-                  args.iterate > 1 else 'calibrated model',
-                  effective_GBps=valid * abytes / (wall / args.steps) / 1e9,
+                  depth_split='given (--split)' if split else
+                  'measured (soda_hip_plan_tune)' if not no_tune and
+                  iterate > 1 else 'calibrated model',
+                  effective_GBps=valid * abytes / (wall / steps) / 1e9,
                   device=host.device_info(0)['arch']),
       roofline=roofline_block(spec, program, schedule,
-                              per_iteration_updates(spec, dims, args.iterate),
-                              timing, dims, args.iterate, step_us=ms_per_step * 1e3))
+                              per_iteration_updates(spec, dims, iterate),
+                              timing, dims, iterate, step_us=ms_per_step * 1e3))
   for d in din + dout:
     d.free()
   program.close()
+  return result, spec
+
+
+OTHER_ROOFLINE_KEYS = ('kernel', 'bound', 'frac', 'unit', 'frac_algorithmic', 'traffic',
+                       'hbm_measured_frac', 'hbm_floor_frac', 'valu_frac', 'kernel_avg_us',
+                       'kernel_launches', 'shader_clock_ghz', 'useful_instruction_share')
+
+
+def other_config_entry(tag, line):
+  """The condensed form of a bench line under config.other_configs."""
+  rf = line['roofline']
+  return dict(config=tag, workload=line['config']['workload'], ms=line['ms_per_step'],
+              gcell_updates_per_s=line['value'], steps=line['steps'],
+              warmup=line['warmup'], launches=line['config']['launches_per_step'],
+              depth_schedule=line['config']['depth_schedule'],
+              effective_GBps=line['config']['effective_GBps'],
+              roofline={k: rf.get(k) for k in OTHER_ROOFLINE_KEYS})
+
+
+def is_headline(args):
+  return args.app == 'jacobi2d' and list(args.size) == [16384, 16384] and \
+      args.iterate == 1000
+
+
+def run_single(args):
+  result, spec = measure(args.app, args.size, args.iterate, args.steps, args.warmup,
+                         max_depth=args.max_depth, split=args.split,
+                         no_tune=args.no_tune, jit=args.jit)
+  if is_headline(args) and not args.no_other_configs and not args.split:
+    others = []
+    for tag, app, dims, iterate in OTHER_CONFIGS:
+      line, _ = measure(app, dims, iterate, OTHER_STEPS, OTHER_WARMUP, jit=args.jit)
+      others.append(other_config_entry(tag, line))
+    result['config']['other_configs'] = others
   if args.cpu_seconds > 0:
-    result['cpu_baseline'] = cpu_baseline(spec, dims, args.cpu_seconds)
+    result['cpu_baseline'] = cpu_baseline(spec, list(args.size), args.cpu_seconds)
   return result
 
 

@@ -78,7 +78,9 @@ struct soda_hip_plan {
   std::vector<soda_hip_kernel> kernels;
   std::vector<hipFunction_t> funcs;
   std::vector<int> resident_blocks;  // per kernel: workgroups the chip holds at once
+  std::vector<int> static_lds;       // per kernel: bytes of LDS the code object declares
   int cus = 256;                     // compute units of the device the plan lives on
+  int64_t lds_per_cu = 160 * 1024;   // LDS of one CU (gfx950: 160 KiB)
   int max_depth = 0;
   int chunk_rows_override = 0;       // SODA_HIP_CHUNK_ROWS, for tuning
   // shortest chunk the launcher considers: small grids need many short chunks to
@@ -280,6 +282,7 @@ const double kStreamingMiB = 512.0;
 // beyond this a launch's box does not fit the 256 MiB Infinity Cache (the kernels' own
 // non-temporal paths switch at the same figure: kernel_common.NT_STREAMING_BYTES)
 const double kBeyondCacheBytes = 288.0 * 1024 * 1024;
+const int64_t kMaxGridYZ = 65535;      // workgroups along grid.y / grid.z
 
 // `resident` = workgroups of this launch the chip holds at once (the kernel's occupancy,
 // or less under a cap on workgroups per CU; 0 = the kernel's occupancy)
@@ -377,8 +380,17 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
       // with dynamic LDS the kernel never uses, 160 KiB / (cap + 1) + 1 KiB each
       const int cap = streaming_cap(plan, k, footprint_of(plan, args));
       if (cap > 0 && resident > (int64_t)cap * plan->cus) {
-        resident = (int64_t)cap * plan->cus;
-        out->lds_bytes = 160u * 1024u / (unsigned)(cap + 1) + 1024u;
+        // each workgroup must take more than 1 / (cap + 1) of the CU's LDS and at most
+        // 1 / cap of it, its static LDS included; a cap the padding cannot realise (the
+        // static part alone already excludes `cap` workgroups) is not applied
+        const int64_t lds_cu = plan->lds_per_cu, fixed = plan->static_lds[k];
+        const int64_t granule = 1024;
+        int64_t total = lds_cu / (cap + 1) / granule * granule + granule;   // > lds_cu / (cap + 1)
+        total = std::max(total, (fixed + granule - 1) / granule * granule);
+        if (total * cap <= lds_cu) {
+          resident = (int64_t)cap * plan->cus;
+          out->lds_bytes = (unsigned)std::max<int64_t>(0, total - fixed);
+        }
       }
       int64_t best = tile, best_cost = -1;
       const double footprint = footprint_of(plan, args);
@@ -406,6 +418,9 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
           plan->chunk_rows_override == 0)
         best = std::max<int64_t>(1, std::min<int64_t>(desc.stream_chunk, extent));
       if (plan->chunk_rows_override > 0) best = plan->chunk_rows_override;
+      // ... but never so short that the chunks outnumber what one grid dimension takes
+      // (a 256 x 1M box in chunks of 8 rows would be 125 000 workgroups along y)
+      best = std::max<int64_t>(best, (extent + kMaxGridYZ - 1) / kMaxGridYZ);
       tile = best;
       out->args.param[0] = best;
       const double blocks = (double)inner * (double)((extent + best - 1) / best);
@@ -1095,6 +1110,7 @@ int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* progra
       int regs = 0, dev = 0, cus = 256;
       (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, pl->funcs[k]);
       hipDeviceProp_t prop;
+      memset(&prop, 0, sizeof prop);
       if (hipGetDevice(&dev) == hipSuccess &&
           hipGetDeviceProperties(&prop, dev) == hipSuccess)
         cus = prop.multiProcessorCount;
@@ -1115,6 +1131,17 @@ int soda_hip_plan_create(soda_hip_module* module, const soda_hip_program* progra
                 waves_per_block);
       pl->resident_blocks.push_back(std::max(1, cus * per_cu));
       pl->cus = cus;
+      int lds = 0;
+      (void)hipFuncGetAttribute(&lds, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, pl->funcs[k]);
+      pl->static_lds.push_back(std::max(0, lds));
+      // (gfx950 has 160 KiB per CU; a runtime that reports the per-workgroup limit of
+      // older parts here must not loosen the cap)
+      pl->lds_per_cu = std::max<int64_t>(160 * 1024,
+                                         (int64_t)prop.maxSharedMemoryPerMultiProcessor);
+      if (tuning_env("SODA_HIP_DEBUG"))
+        fprintf(stderr, "soda_hip: kernel %s: %d bytes of static LDS; device reports %lld "
+                "bytes of LDS per CU\n", pl->kernels[k].name, lds,
+                (long long)prop.maxSharedMemoryPerMultiProcessor);
     }
     const soda_hip_kernel& d = pl->kernels[k];
     if (d.block[0] < 1 || d.block[1] < 1 || d.block[2] < 1 ||

@@ -514,8 +514,8 @@ def generate(spec, max_depth=None, cols=None, chunk_rows=None, prefetch=None,
     # single-wave, 221 / 222 us block form (one read and one write of the array at 5.3
     # TB/s: 203 us); 256^3 67 / 65 against 33 / 35; heat3d 512^3 depth 2 464 -> 231.
     deep_from = fused_options.get('deep3d_from', 1)
-    deep = [d for d in (depths if depths is not None else
-                        BLOCK_3D_SHALLOW_DEPTHS + DEEP_3D_DEPTHS)
+    deep = [d for d in sorted(set(depths if depths is not None else
+                                  BLOCK_3D_SHALLOW_DEPTHS + DEEP_3D_DEPTHS))
             if d >= deep_from and d <= max(1, spec['iterate'])]
     if len(spec['inputs']) == len(spec['outputs']) == 1 and (
         depths is not None or arithmetic_weight(spec) <= DEEP_3D_MAX_WEIGHT):

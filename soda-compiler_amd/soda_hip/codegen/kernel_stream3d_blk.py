@@ -96,7 +96,7 @@ ALIGN_OUT = 16      # cells: output tiles start and end on 64-byte pieces
 
 def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
          vgpr_budget=250, ring=0, pairs=0, stamps=0, mask_loads=0, nt=0,
-         wide_stores=0, lean_fill=0):
+         wide_stores=0, lean_fill=0, prio=0):
   """Returns (text, kernel table entry).
 
   `prefetch` = input planes loaded ahead into REGISTERS (R*C VGPRs each);
@@ -752,6 +752,12 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('  const int wave = __builtin_amdgcn_readfirstlane('
        '__builtin_amdgcn_workitem_id_x() >> 6);')
   # (a 1-D grid: the kernel places its tiles itself, XCD by XCD)
+  if prio:
+    # issue priority by band: the two wavefronts a SIMD holds - bands w and w + G / 2 -
+    # run the same code in the same phase and wait together; a raised priority for one of
+    # them staggers them (1: the first half of the bands, 2: the second half)
+    line('  if (%s) __builtin_amdgcn_s_setprio(3);' % (
+        'wave < %d' % (G // 2) if prio == 1 else 'wave >= %d' % (G // 2)))
   line('  const unsigned L = __builtin_amdgcn_workgroup_id_x();')
   line('  const unsigned SX = (unsigned)a.param[1] & 0xffffu, '
        'SY = (unsigned)a.param[1] >> 16;')
@@ -820,6 +826,8 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     entry['mask_loads'] = 1
   if lean_fill:
     entry['lean_fill'] = 1
+  if prio:
+    entry['prio'] = int(prio)
   if wide_stores:
     entry['wide_stores'] = int(wide_stores)
   return '\n'.join(o) + '\n', entry

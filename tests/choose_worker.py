@@ -25,9 +25,10 @@ def main():
   mine = dict(zip(candidates, times[rank]))
   calls = []
 
-  def time_step(exchange, overlapped):
+  def time_step(exchange, overlapped, repeats):
     calls.append((exchange, overlapped))
-    return mine[(exchange, overlapped)]
+    # (noisy repeats around the rank's figure: the fastest one counts)
+    return [mine[(exchange, overlapped)] * (1.0 + 0.1 * k) for k in range(repeats)]
 
   def reduce_max(seconds):
     t = torch.tensor(list(seconds), dtype=torch.float64)

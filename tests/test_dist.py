@@ -140,13 +140,27 @@ def test_choose_exchange_takes_the_fastest_row_of_the_slowest_ranks():
   seconds = {(24, False): 0.031, (24, True): 0.034, (48, False): 0.029, (48, True): 0.030}
   # (a second rank that is slower on the locally fastest pair)
   other = {(24, False): 0.030, (24, True): 0.030, (48, False): 0.040, (48, True): 0.0305}
-  table, chosen = sdist.choose_exchange(
-      pairs, lambda e, o: seconds[(e, o)],
-      lambda mine: [max(m, other[p]) for m, p in zip(mine, pairs)])
+  calls = []
+
+  def time_step(e, o, repeats):
+    calls.append(repeats)
+    return [seconds[(e, o)] * f for f in (1.3, 1.0, 1.1)[:repeats]]   # the fastest counts
+  reduce_max = lambda mine: [max(m, other[p]) for m, p in zip(mine, pairs)]   # noqa: E731
+  table, chosen = sdist.choose_exchange(pairs, time_step, reduce_max)
+  assert calls == [sdist.EXCHANGE_REPEATS] * 4 and sdist.EXCHANGE_REPEATS >= 3
   assert [(r['exchange'], r['overlapped']) for r in table] == pairs
   assert [round(r['ms'], 3) for r in table] == [31.0, 34.0, 40.0, 30.5]
+  assert all(r['repeats'] == sdist.EXCHANGE_REPEATS for r in table)
   assert (chosen['exchange'], chosen['overlapped']) == (48, True)
   assert chosen['ms'] == min(r['ms'] for r in table)
+  # the incumbent (default period, serial) is kept unless a candidate beats it by the
+  # margin: 30.5 against 31.0 ms is 1.6 %
+  _, kept = sdist.choose_exchange(pairs, time_step, reduce_max, incumbent=(24, False))
+  assert (kept['exchange'], kept['overlapped']) == (24, False)
+  _, moved = sdist.choose_exchange(pairs, time_step, reduce_max, incumbent=(24, True))
+  assert (moved['exchange'], moved['overlapped']) == (48, True)       # 34.0 -> 30.5
+  _, free = sdist.choose_exchange(pairs, time_step, reduce_max, incumbent=(96, False))
+  assert (free['exchange'], free['overlapped']) == (48, True)         # not in the table
 
 
 def test_all_ranks_choose_the_same_exchange(tmp_path):

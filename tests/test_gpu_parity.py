@@ -867,6 +867,24 @@ def test_per_stage_kernels_beyond_the_grid_limit():
   assert np.array_equal(staged[1:-1, 1:-1, 1:-1], want[1:-1, 1:-1, 1:-1])
 
 
+def test_tall_narrow_streaming_box_beyond_the_grid_limit():
+  """A streaming launch beyond the Infinity Cache walks the kernel's MEASURED chunk
+  (soda_hip_kernel.stream_chunk: 8-32 rows), and 600 000 rows in chunks of 8 would be
+  75 000 workgroups along grid.y (limit 65535): the launcher lengthens the chunk instead
+  of failing with buffer_extents_too_large (round-4 advice); results as the oracle's."""
+  prog = program('jacobi2d')
+  rows, cols = 600000, 256                  # 2 x 586 MiB: beyond the cache
+  prog.set_max_depth(1)
+  sched = prog.schedule([cols, rows], 1)
+  assert [e['name'] for e, _ in sched] == ['jacobi2d_fused_k1']
+  assert sched[0][0].get('stream_chunk', 0) * 65535 < rows       # the case the advice names
+  a = np.random.default_rng(14).random((rows, cols), dtype=np.float32)
+  got = prog.run_numpy([a], iterate=1)[0]
+  want = oracle('jacobi2d').run([a], iterate=1)['t0']
+  prog.set_max_depth(0)
+  assert np.array_equal(got[1:-1, 1:-1], want[1:-1, 1:-1])
+
+
 def test_half_program_against_ieee_binary16_arithmetic():
   """`half` programs have no reference answer here (the reference's golden loop
   needs Xilinx's hls_half.h, g++ 11 has no _Float16 in C++): they are checked against
@@ -1364,6 +1382,43 @@ def test_bench_py_one_rank_group_over_real_rccl():
   from soda_hip.codegen import spec as specmod
   valid = specmod.valid_cells(spec, [4096, 2000], 60)
   assert abs(d['value'] - valid / (d['ms_per_step'] * 1e-3) / 1e9) < 1e-6 * d['value']
+
+
+def test_bench_py_headline_line_carries_the_other_single_gpu_configs():
+  """The driver's own command (`python bench.py --steps 2 --warmup 1`) prints the headline
+  workload and, under config.other_configs, BASELINE configs 2, 3 and 5 timed on the same
+  device in the same process ("plus cfg 2, 3, 5 single-point numbers")."""
+  import subprocess
+  import sys
+  from conftest import ROOT
+  r = subprocess.run(
+      [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1',
+       '--cpu-seconds', '0'], capture_output=True, text=True, timeout=900,
+      env={k: v for k, v in os.environ.items()
+           if k not in ('SODA_DIST_BACKEND', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK')})
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+  assert len(lines) == 1, r.stdout[-2000:]
+  d = json.loads(lines[0])
+  assert d['config']['workload'] == 'jacobi2d.soda float32 16384x16384, iterate 1000'
+  assert d['roofline']['kernel'].startswith('jacobi2d_fused_k')
+  others = d['config']['other_configs']
+  assert [o['config'] for o in others] == ['cfg2', 'cfg3', 'cfg5']
+  assert [o['workload'] for o in others] == [
+      'jacobi2d.soda float32 8192x8192, iterate 100',
+      'blur.soda uint16 16384x16384, iterate 1',
+      'jacobi3d.soda float32 512x512x512, iterate 200']
+  from soda_hip.codegen import spec as specmod
+  for o, (app, dims, iterate) in zip(others, (('jacobi2d', [8192, 8192], 100),
+                                              ('blur', [16384, 16384], 1),
+                                              ('jacobi3d', [512, 512, 512], 200))):
+    valid = specmod.valid_cells(gpu_util.load_spec(app, iterate=iterate), dims, iterate)
+    assert abs(o['gcell_updates_per_s'] - valid / (o['ms'] * 1e-3) / 1e9) < 1e-6 * valid
+    assert o['steps'] == 30 and o['warmup'] == 10 and 0 < o['ms'] < 50
+    rf = o['roofline']
+    assert rf['bound'] in ('hbm', 'valu') and 0 < rf['frac'] <= 1.0
+    assert rf['frac_algorithmic'] > 0 and rf['kernel_avg_us'] * rf['kernel_launches'] \
+        <= 1.001 * o['ms'] * 1e3
 
 
 def test_denormals_signed_zeros_and_infinities():

@@ -102,3 +102,29 @@ def test_stats_pass_reproduces_the_bench_line():
     for name, calls in check['calls_expected'].items():
       assert stats[name]['calls'] == calls, (name, stats[name]['calls'], calls)
     assert abs(check['ratio'] - 1) < 0.02, check
+
+
+def test_other_configs_block_has_the_shape_the_driver_line_promises():
+  """bench.py at N = 1 prints BASELINE configs 2, 3 and 5 under config.other_configs
+  (condensed lines: time, rate, schedule, the dominant kernel's roofline figures); only
+  the headline workload carries them."""
+  import argparse
+  assert [(t, a, d, i) for t, a, d, i in bench.OTHER_CONFIGS] == [
+      ('cfg2', 'jacobi2d', [8192, 8192], 100), ('cfg3', 'blur', [16384, 16384], 1),
+      ('cfg5', 'jacobi3d', [512, 512, 512], 200)]
+  line = dict(ms_per_step=0.95, value=6900.0, steps=30, warmup=10,
+              config=dict(workload='jacobi2d.soda float32 8192x8192, iterate 100',
+                          launches_per_step=5, depth_schedule='5x20', effective_GBps=55000.0),
+              roofline=dict(kernel='jacobi2d_fused_k20', bound='valu', frac=0.46, unit='Tlane-op/s',
+                            frac_algorithmic=7.2, traffic=None, hbm_measured_frac=None,
+                            hbm_floor_frac=0.36, valu_frac=0.46, kernel_avg_us=188.0,
+                            kernel_launches=5, extra='dropped'))
+  e = bench.other_config_entry('cfg2', line)
+  assert e['config'] == 'cfg2' and e['ms'] == 0.95 and e['gcell_updates_per_s'] == 6900.0
+  assert e['depth_schedule'] == '5x20' and e['launches'] == 5
+  assert set(e['roofline']) == set(bench.OTHER_ROOFLINE_KEYS)
+  assert e['roofline']['bound'] == 'valu' and e['roofline']['shader_clock_ghz'] is None
+  ns = argparse.Namespace(app='jacobi2d', size=[16384, 16384], iterate=1000)
+  assert bench.is_headline(ns)
+  assert not bench.is_headline(argparse.Namespace(app='jacobi2d', size=[8192, 8192], iterate=100))
+  assert not bench.is_headline(argparse.Namespace(app='blur', size=[16384, 16384], iterate=1000))

@@ -21,7 +21,8 @@ prog = host.open_program(source=text, spec=spec)
 orc = soda_oracle.Oracle(spec)
 ok = True
 for iterate, shape in ((4, (30, 64, 128)), (9, (45, 131, 140)), (13, (150, 70, 257)), (1, (20, 64, 130)),
-                       (2, (37, 100, 200)), (6, (64, 64, 128)), (8, (100, 200, 300))):
+                       (2, (37, 100, 200)), (6, (64, 64, 128)), (8, (100, 200, 300)),
+                       (5, (21, 72, 128)), (12, (40, 80, 140)), (7, (50, 150, 260))):
   a = np.random.default_rng(3).random(shape, dtype=np.float32)
   want = orc.run([a], iterate=iterate)[spec['outputs'][0]]
   sl = orc.valid_slices(tuple(reversed(shape)), iterate)
