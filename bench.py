@@ -242,7 +242,7 @@ HBM_ACHIEVABLE_FRAC = 6.29 / 8.0
 
 
 def roofline_block(spec, program, schedule, updates, timing, dims, iterate,
-                   step_us=None):
+                   step_us=None, clock=None):
   """`schedule` = [(kernel entry, modelled us)] as issued, `updates` = valid
   cell-updates of each iteration of the sweep that `timing` timed; `step_us` = wall
   time of one un-instrumented sweep (the timed loop).
@@ -323,7 +323,11 @@ def roofline_block(spec, program, schedule, updates, timing, dims, iterate,
           sq['valu_instructions']
     if sq.get('shader_cycles'):
       block['shader_cycles_per_launch'] = sq['shader_cycles']
-      block['shader_clock_ghz'] = sq['shader_cycles'] / (avg_s * 1e9)
+  # the clock this run held under the load (measured beside the sweeps, not a counter
+  # file): valu_frac = VALU issue utilisation x useful share x shader_clock_ghz / 2.4
+  if clock:
+    block['shader_clock_ghz'] = clock['ghz']
+    block['shader_clock_probe_ms'] = clock['seconds'] * 1e3
   if valu_binds:
     block.update(bound='valu', achieved=valu, peak=VALU_PEAK_TLANEOPS,
                  unit='Tlane-op/s', frac=block['valu_frac'])
@@ -415,6 +419,13 @@ def measure(app, dims, iterate, steps, warmup, max_depth=0, split='', no_tune=Fa
   # every launch at its fastest
   timing = program.sweep_timed(ip, op, dims, iterate, warmup=0, repeats=3)
   schedule = program.schedule(dims, iterate)
+  # the shader clock under this load, measured in-run: a probe wavefront sleeps beside
+  # ~30 ms of the same sweeps and counts shader cycles against the constant 100 MHz clock
+  probe_sweeps = max(1, int(0.03 / max(wall / steps, 1e-6)))
+  clock = program.shader_clock_during(
+      lambda: [program.sweep(ip, op, dims, iterate) for _ in range(probe_sweeps)],
+      probe_sweeps * wall / steps)
+  sync()
   valid = specmod.valid_cells(spec, dims, iterate)
   nominal = cells * iterate
   ms_per_step = wall / steps * 1e3
@@ -441,7 +452,8 @@ def measure(app, dims, iterate, steps, warmup, max_depth=0, split='', no_tune=Fa
                   device=host.device_info(0)['arch']),
       roofline=roofline_block(spec, program, schedule,
                               per_iteration_updates(spec, dims, iterate),
-                              timing, dims, iterate, step_us=ms_per_step * 1e3))
+                              timing, dims, iterate, step_us=ms_per_step * 1e3,
+                              clock=clock))
   for d in din + dout:
     d.free()
   program.close()

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SODA_HIP_ABI_VERSION 6
+#define SODA_HIP_ABI_VERSION 7
 #define SODA_HIP_MAX_DIMS 4
 #define SODA_HIP_MAX_TENSORS 16 /* inputs + stages of one program */
 #define SODA_HIP_MAX_IO 8
@@ -310,8 +310,15 @@ int soda_hip_plan_set_max_depth(soda_hip_plan* plan, int max_depth);
  * kernel in turn is priced 12 % lower or higher, runs every distinct candidate as a
  * whole sweep (in -> out, as soda_hip_sweep; one untimed run, then the faster of two)
  * and remembers the fastest: later sweeps and schedules with the same dims and
- * `iterate` use it.  A split can only change speed, never results.  Synchronous; a
- * few sweeps' worth of time (the untimed warm-up run of the reference protocol,
+ * `iterate` use it.  A split can only change speed, never results.
+ * Then the MEMORY-BOUND launches of that schedule (kernels that carry a measured chunk
+ * length, soda_hip_kernel.stream_chunk, on boxes beyond the Infinity Cache): the
+ * calibrated chunk length x cap on workgroups per CU was measured on one box, and boxes
+ * differ by more than the gain - so the calibrated pair is timed against the chunk's two
+ * neighbours on the calibration ladder (8, 12, 16, 24, 32, 48, ... rows) and the other
+ * cap, whole sweeps again, and a pair that beats it by more than 1 % is kept per (kernel,
+ * box extents).  Chunking cannot change results either.  Synchronous; a few dozen
+ * sweeps' worth of time (the untimed warm-up run of the reference protocol,
  * host.py:775-790, is the natural place for it). */
 int soda_hip_plan_tune(soda_hip_plan* plan, void* const* in, void* const* out,
                        const int64_t dims[SODA_HIP_MAX_DIMS], int iterate,
@@ -335,6 +342,19 @@ int soda_hip_plan_set_split(soda_hip_plan* plan, const int64_t dims[SODA_HIP_MAX
  * soda_hip/runtime/dist.py) needs this: an intermediate box of one piece would
  * reach into rows another piece has already finished. */
 int soda_hip_plan_set_out_final_only(soda_hip_plan* plan, int on);
+
+/* ---- shader clock under load ------------------------------------------------
+ * The deep kernels are bound by VALU issue, and the clock the chip holds under their
+ * load (2.0-2.2 of 2.4 GHz) is one of the factors between their rate and the peak's
+ * (bench.py: roofline.shader_clock_ghz).  _start launches ONE wavefront of the blob's
+ * `soda_hip_clock_probe` kernel on a stream the plan owns: it sleeps for `spins` x ~8 k
+ * shader cycles (~4 us each) beside whatever the caller enqueues next, counting shader
+ * cycles (s_memtime) and ticks of the constant 100 MHz clock (s_memrealtime).  _finish
+ * waits for it and returns cycles / time.  No reference counterpart (the reference reads
+ * OpenCL profiling events, host.py:775-800); SODA_HIP_ERR_NO_KERNEL for blobs built
+ * before ABI 7. */
+int soda_hip_clock_probe_start(soda_hip_plan* plan, int spins);
+int soda_hip_clock_probe_finish(soda_hip_plan* plan, double* shader_ghz, double* seconds);
 
 /* ---- multi-GPU: one slab of a larger grid ------------------------------------
  * The reference has nothing distributed (one FPGA); what must be preserved is its
@@ -361,7 +381,23 @@ typedef struct soda_hip_slab {
   int32_t exchange;           /* iterations between ghost exchanges (>= 1) */
   int64_t dims[SODA_HIP_MAX_DIMS]; /* the GLOBAL grid */
   int64_t own_first, own_last;     /* this rank's rows of the outermost dimension */
+  int32_t order;                   /* SODA_HIP_SLAB_SERIAL or SODA_HIP_SLAB_BANDS_FIRST (ABI 7) */
+  int32_t reserved;                /* 0 */
 } soda_hip_slab;
+
+/* How soda_hip_run_slab orders a super-step's exchange against its sweeps (the same two
+ * orders as soda_hip/runtime/dist.py: SerialSchedule / StreamSchedule):
+ *   SERIAL       exchange on `stream`, then one sweep of the whole slab;
+ *   BANDS_FIRST  every super-step but the last first sweeps the two bands of rows the
+ *                neighbours are waiting for (sub-arrays of 3 E r rows, cut inside valid
+ *                data), hands them to the NEXT super-step's exchange on a second stream
+ *                the plan owns (events both ways) and sweeps the interior meanwhile; a
+ *                piece writes its destination with its last launch only
+ *                (soda_hip_plan_set_out_final_only), so intermediate launches never touch
+ *                rows that are being sent.  Slabs too thin for bands (own rows <=
+ *                2 x the rows sent) sweep whole and then exchange.  Same results. */
+#define SODA_HIP_SLAB_SERIAL 0
+#define SODA_HIP_SLAB_BANDS_FIRST 1
 
 /* The exchange period every rank of an even cut uses (soda_hip/runtime/dist.py:
  * SlabPlan applies the same rule): a ghost region cannot be deeper than the smallest
@@ -382,7 +418,12 @@ int soda_hip_slab_extent(const soda_hip_plan* plan, const soda_hip_slab* slab,
  * never written except for its ghost rows; b, c: two more arrays of the same
  * size.  comm: an ncclComm_t of `world` ranks (NULL when world == 1).  *result
  * receives b or c, whichever holds the rank's own rows after `iterate`
- * iterations.  Asynchronous on `stream`. */
+ * iterations.  Asynchronous on `stream`.
+ * Failure: a rank that fails here (a launch, an allocation, an RCCL error, a bad
+ * descriptor) would leave its neighbours blocked in ncclRecv, so with world > 1 ANY error
+ * return means the communicator has been aborted (ncclCommAbort) first: the peers'
+ * pending and later operations on it fail, their calls return an error as well, and
+ * `comm` must not be used again (nor aborted or destroyed a second time). */
 int soda_hip_run_slab(soda_hip_plan* plan, const soda_hip_slab* slab, void* comm,
                       void* a, void* b, void* c, int iterate, void* stream,
                       void** result, int* exchanges);

@@ -108,11 +108,23 @@ struct soda_hip_plan {
   // margins of a resumed or sharded run move the boxes by a few cells, not the
   // ranking); where an entry exists build_schedule uses it instead of its own split
   std::map<std::array<int64_t, 5>, std::vector<int>> tuned_split;
+  // soda_hip_plan_tune, streaming launches: the (chunk length, workgroups per CU) that
+  // ran fastest on THIS device for a kernel on a box of these extents, keyed by kernel
+  // index + box extents; make_launch uses it instead of the kernel's calibration record
+  // (stream_chunk / stream_wgs_per_cu were measured on one box of one round)
+  std::map<std::array<int64_t, 5>, std::array<int, 2>> tuned_stream;
   // while tuning: the modelled price of kernels of this depth is scaled by this
   // factor (how the candidate splits are generated); 0 = no bias
   int bias_depth = 0;
   double bias = 1.0;
   bool tuning = false;               // candidates are being timed: ignore tuned_split
+  // soda_hip_run_slab, bands-first order: the exchange runs on a stream the plan owns
+  hipStream_t side = nullptr;
+  hipEvent_t ev_main = nullptr, ev_landed = nullptr;
+  // soda_hip_clock_probe_start / _finish
+  hipFunction_t probe = nullptr;
+  void* probe_buf = nullptr;
+  bool probe_running = false;
 };
 
 namespace {
@@ -334,6 +346,12 @@ int streaming_cap(const soda_hip_plan* plan, int k, double footprint) {
   return std::max(0, (int)plan->kernels[k].stream_wgs_per_cu);
 }
 
+std::array<int64_t, 5> stream_key(const soda_hip_plan* plan, int k, const soda_hip_args& args) {
+  std::array<int64_t, 5> key = {k, 1, 1, 1, 1};
+  for (int d = 0; d < plan->prog.dim && d < 4; ++d) key[1 + d] = args.box_hi[d] - args.box_lo[d];
+  return key;
+}
+
 int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
                 Launch* out, bool* empty) {
   const soda_hip_kernel& desc = plan->kernels[k];
@@ -378,7 +396,16 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
       // memory-bound kernels: fewer wavefronts walking longer chunks keep the set of
       // DRAM pages the chip touches at a time small - tools/copyceil.hip): enforced
       // with dynamic LDS the kernel never uses, 160 KiB / (cap + 1) + 1 KiB each
-      const int cap = streaming_cap(plan, k, footprint_of(plan, args));
+      int cap = streaming_cap(plan, k, footprint_of(plan, args));
+      int64_t tuned_chunk = 0;
+      if (desc.stream_chunk > 0 && footprint_of(plan, args) > kBeyondCacheBytes &&
+          plan->chunk_rows_override == 0 && plan->wgs_per_cu_cap == 0) {
+        const auto tuned = plan->tuned_stream.find(stream_key(plan, k, args));
+        if (tuned != plan->tuned_stream.end()) {
+          tuned_chunk = tuned->second[0];
+          cap = tuned->second[1];
+        }
+      }
       if (cap > 0 && resident > (int64_t)cap * plan->cus) {
         // each workgroup must take more than 1 / (cap + 1) of the CU's LDS and at most
         // 1 / cap of it, its static LDS included; a cap the padding cannot realise (the
@@ -416,7 +443,8 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
       // (tuning: SODA_HIP_CHUNK_ROWS = N forces N, -1 the rule above whatever the kernel says)
       if (desc.stream_chunk > 0 && footprint > kBeyondCacheBytes &&
           plan->chunk_rows_override == 0)
-        best = std::max<int64_t>(1, std::min<int64_t>(desc.stream_chunk, extent));
+        best = std::max<int64_t>(1, std::min<int64_t>(
+            tuned_chunk > 0 ? tuned_chunk : desc.stream_chunk, extent));
       if (plan->chunk_rows_override > 0) best = plan->chunk_rows_override;
       // ... but never so short that the chunks outnumber what one grid dimension takes
       // (a 256 x 1M box in chunks of 8 rows would be 125 000 workgroups along y)
@@ -861,6 +889,64 @@ int launch_one(const soda_hip_plan* plan, const Launch& l, hipStream_t stream) {
   return 0;
 }
 
+// Streaming launches of the schedule (kernels that name a measured chunk, on boxes beyond
+// the Infinity Cache): the calibrated (chunk, workgroups per CU) against the chunk's two
+// neighbours on the calibration ladder and the other cap, each as a WHOLE sweep on this
+// device; the fastest is kept per (kernel, box extents) when it beats the calibrated pair
+// by more than 1 % (tools/calibrate.py measured those on one box; boxes differ).
+template <typename TimeSweep>
+int tune_streaming(soda_hip_plan* plan, const int64_t* dims, int iterate,
+                   const int32_t* valid_lo, const int32_t* valid_hi, TimeSweep time_sweep) {
+  if (plan->chunk_rows_override != 0 || plan->wgs_per_cu_cap != 0) return 0;
+  std::vector<Launch> list;
+  int depth = 0;
+  int rc = build_schedule(plan, nullptr, nullptr, dims, iterate, valid_lo, valid_hi, &list,
+                          &depth, nullptr, true);
+  if (rc) return rc;
+  static const int ladder[] = {8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
+  const int n_ladder = (int)(sizeof ladder / sizeof ladder[0]);
+  std::vector<std::array<int64_t, 5>> seen;
+  for (const Launch& l : list) {
+    const soda_hip_kernel& desc = plan->kernels[l.kernel];
+    if (desc.fill_rows <= 0 || desc.stream_chunk <= 0 ||
+        footprint_of(plan, l.args) <= kBeyondCacheBytes)
+      continue;
+    const std::array<int64_t, 5> key = stream_key(plan, l.kernel, l.args);
+    if (std::find(seen.begin(), seen.end(), key) != seen.end()) continue;
+    seen.push_back(key);
+    plan->tuned_stream.erase(key);
+    int at = 0;
+    for (int i = 0; i < n_ladder; ++i)
+      if (std::abs(ladder[i] - (int)desc.stream_chunk) < std::abs(ladder[at] - (int)desc.stream_chunk))
+        at = i;
+    const int cap0 = std::max(0, (int)desc.stream_wgs_per_cu);
+    std::vector<std::array<int, 2>> candidates = {{(int)desc.stream_chunk, cap0}};
+    for (int cap : {cap0, cap0 == 2 ? 0 : 2})
+      for (int i : {at - 1, at, at + 1}) {
+        if (i < 0 || i >= n_ladder) continue;
+        const std::array<int, 2> c = {ladder[i], cap};
+        if (std::find(candidates.begin(), candidates.end(), c) == candidates.end())
+          candidates.push_back(c);
+      }
+    float incumbent = 0, best_ms = 0;
+    size_t best = 0;
+    for (size_t c = 0; c < candidates.size() && !rc; ++c) {
+      if (c) plan->tuned_stream[key] = candidates[c];
+      float ms = 0;
+      rc = time_sweep(3, &ms);
+      if (c == 0) incumbent = best_ms = ms;
+      else if (ms < best_ms) { best_ms = ms; best = c; }
+      if (tuning_env("SODA_HIP_DEBUG"))
+        fprintf(stderr, "soda_hip: tune stream %s box %lld x %lld: chunk %d cap %d -> %.1f us\n",
+                desc.name, (long long)key[1], (long long)key[2], candidates[c][0],
+                candidates[c][1], ms * 1000.0);
+    }
+    if (!rc && best > 0 && best_ms < incumbent * 0.99f) plan->tuned_stream[key] = candidates[best];
+    else plan->tuned_stream.erase(key);
+  }
+  return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1167,6 +1253,10 @@ int soda_hip_plan_destroy(soda_hip_plan* plan) {
   for (void* ptr : plan->scratch_b)
     if (ptr && hipFree(ptr) != hipSuccess)
       rc = fail(SODA_HIP_ERR_DEVICE_FREE, "hipFree of plan scratch failed");
+  if (plan->probe_buf) (void)hipFree(plan->probe_buf);
+  if (plan->ev_main) (void)hipEventDestroy(plan->ev_main);
+  if (plan->ev_landed) (void)hipEventDestroy(plan->ev_landed);
+  if (plan->side) (void)hipStreamDestroy(plan->side);
   delete plan;
   return rc;
 }
@@ -1225,10 +1315,30 @@ int soda_hip_plan_tune(soda_hip_plan* plan, void* const* in, void* const* out,
   plan->bias_depth = 0;
   plan->bias = 1.0;
   plan->tuning = false;
-  if (rc || candidates.size() < 2) return rc;     // nothing to choose from
+  if (rc) return rc;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
     return fail(SODA_HIP_ERR_DEVICE_RUN, "hipEventCreate failed");
+  // the fastest of `runs` whole sweeps after one untimed one, in milliseconds
+  auto time_sweep = [&](int runs, float* fastest) -> int {
+    int e = 0;
+    for (int run = 0; run <= runs && !e; ++run) {
+      if (hipEventRecord(e0, s) != hipSuccess) e = fail(SODA_HIP_ERR_DEVICE_RUN, "hipEventRecord failed");
+      if (!e) e = soda_hip_sweep(plan, in, out, dims, iterate, valid_lo, valid_hi, stream);
+      if (!e && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess))
+        e = fail(SODA_HIP_ERR_DEVICE_SYNC, "timing a tuning sweep failed");
+      float ms = 0;
+      if (!e) (void)hipEventElapsedTime(&ms, e0, e1);
+      if (run == 1 || (run > 1 && ms < *fastest)) *fastest = ms;
+    }
+    return e;
+  };
+  if (candidates.size() < 2) {      // one split only: the streaming launches remain
+    rc = tune_streaming(plan, dims, iterate, valid_lo, valid_hi, time_sweep);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+  }
   // every candidate as a whole sweep, in context: one untimed run, then the faster
   // of two timed ones
   size_t best = 0;
@@ -1236,15 +1346,7 @@ int soda_hip_plan_tune(soda_hip_plan* plan, void* const* in, void* const* out,
   for (size_t c = 0; c < candidates.size() && !rc; ++c) {
     plan->tuned_split[key] = candidates[c];
     float fastest = 0;
-    for (int run = 0; run < 3 && !rc; ++run) {
-      if (hipEventRecord(e0, s) != hipSuccess) rc = fail(SODA_HIP_ERR_DEVICE_RUN, "hipEventRecord failed");
-      if (!rc) rc = soda_hip_sweep(plan, in, out, dims, iterate, valid_lo, valid_hi, stream);
-      if (!rc && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess))
-        rc = fail(SODA_HIP_ERR_DEVICE_SYNC, "timing a tuning sweep failed");
-      float ms = 0;
-      if (!rc) (void)hipEventElapsedTime(&ms, e0, e1);
-      if (run == 1 || (run == 2 && ms < fastest)) fastest = ms;
-    }
+    rc = time_sweep(2, &fastest);
     if (tuning_env("SODA_HIP_DEBUG")) {
       fprintf(stderr, "soda_hip: tune %d iteration(s):", iterate);
       for (int d : candidates[c]) fprintf(stderr, " %d", d);
@@ -1252,10 +1354,11 @@ int soda_hip_plan_tune(soda_hip_plan* plan, void* const* in, void* const* out,
     }
     if (c == 0 || fastest < best_ms) { best = c; best_ms = fastest; }
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   if (rc) plan->tuned_split.erase(key);
   else plan->tuned_split[key] = candidates[best];
+  if (!rc) rc = tune_streaming(plan, dims, iterate, valid_lo, valid_hi, time_sweep);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return rc;
 }
 
@@ -1419,6 +1522,47 @@ int soda_hip_sweep_timed(soda_hip_plan* plan, void* const* in, void* const* out,
   return rc;
 }
 
+// ------------------------------------------------------------- clock probe
+int soda_hip_clock_probe_start(soda_hip_plan* plan, int spins) {
+  if (!plan) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "plan is NULL");
+  if (spins < 1) return fail(SODA_HIP_ERR_CONSTRAINT, "spins must be >= 1");
+  if (plan->probe_running) return fail(SODA_HIP_ERR_CONSTRAINT, "a clock probe is running");
+  if (!plan->probe &&
+      hipModuleGetFunction(&plan->probe, plan->module->mod, "soda_hip_clock_probe") != hipSuccess) {
+    plan->probe = nullptr;
+    (void)hipGetLastError();
+    return fail(SODA_HIP_ERR_NO_KERNEL, "the blob holds no soda_hip_clock_probe (built "
+                "before ABI 7)");
+  }
+  if (!plan->side &&
+      hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) != hipSuccess)
+    return fail(SODA_HIP_ERR_DEVICE_RUN, "hipStreamCreate failed");
+  if (!plan->probe_buf) HIP_TRY(SODA_HIP_ERR_DEVICE_MALLOC, hipMalloc(&plan->probe_buf, 16));
+  HIP_TRY(SODA_HIP_ERR_DEVICE_RUN, hipMemsetAsync(plan->probe_buf, 0, 16, plan->side));
+  struct { void* out; int spins; } args = {plan->probe_buf, spins};
+  size_t size = sizeof args;
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE,
+                    &size, HIP_LAUNCH_PARAM_END};
+  HIP_TRY(SODA_HIP_ERR_DEVICE_RUN,
+          hipModuleLaunchKernel(plan->probe, 1, 1, 1, 64, 1, 1, 0, plan->side, nullptr, config));
+  plan->probe_running = true;
+  return 0;
+}
+
+int soda_hip_clock_probe_finish(soda_hip_plan* plan, double* shader_ghz, double* seconds) {
+  if (!plan || !shader_ghz) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  if (!plan->probe_running) return fail(SODA_HIP_ERR_CONSTRAINT, "no clock probe is running");
+  plan->probe_running = false;
+  HIP_TRY(SODA_HIP_ERR_DEVICE_SYNC, hipStreamSynchronize(plan->side));
+  unsigned long long got[2] = {0, 0};
+  HIP_TRY(SODA_HIP_ERR_COPY_TO_HOST, hipMemcpy(got, plan->probe_buf, 16, hipMemcpyDeviceToHost));
+  if (!got[1]) return fail(SODA_HIP_ERR_DEVICE_RUN, "the clock probe reported no time");
+  const double elapsed = (double)got[1] / 100.0e6;      // s_memrealtime: 100 MHz
+  *shader_ghz = (double)got[0] / elapsed / 1e9;
+  if (seconds) *seconds = elapsed;
+  return 0;
+}
+
 // ------------------------------------------------------- multi-GPU slab driver
 namespace {
 
@@ -1429,6 +1573,7 @@ struct Rccl {
   int (*send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
   const char* (*error_string)(int) = nullptr;
+  int (*comm_abort)(void*) = nullptr;
   bool ok = false;
 };
 
@@ -1443,6 +1588,7 @@ const Rccl& rccl() {
     x.send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
     x.recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
     x.error_string = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    x.comm_abort = (int (*)(void*))dlsym(h, "ncclCommAbort");
     x.ok = x.group_start && x.group_end && x.send && x.recv;
     return x;
   }();
@@ -1518,50 +1664,111 @@ int soda_hip_run_slab(soda_hip_plan* plan, const soda_hip_slab* slab, void* comm
                       void** result, int* exchanges) {
   if (!plan || !slab || !a || !b || !c || !result)
     return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
-  if (iterate < 1) return fail(SODA_HIP_ERR_CONSTRAINT, "iterate must be >= 1");
-  SlabGeometry g;
-  int rc = slab_geometry(plan, slab, &g);
-  if (rc) return rc;
-  const soda_hip_program& p = plan->prog;
-  const int last = p.dim - 1;
   if (slab->world > 1 && !comm)
     return fail(SODA_HIP_ERR_NULL_ARGUMENT, "world %d needs an RCCL communicator", slab->world);
   if (slab->world > 1 && !rccl().ok)
     return fail(SODA_HIP_ERR_NO_DEVICE, "librccl.so could not be loaded: %s", dlerror());
+  // From here on a failure of THIS rank would leave its neighbours blocked in ncclRecv
+  // (they wait for rows this rank will never send): whatever fails below, the
+  // communicator is aborted before the error is returned - every peer's pending and
+  // later operation on it then fails instead of waiting - and is invalid afterwards.
+  auto give_up = [&](int rc) {
+    if (rc && slab->world > 1 && comm && rccl().comm_abort) {
+      const std::string keep = g_last_error;
+      (void)rccl().comm_abort(comm);
+      g_last_error = keep + " (communicator aborted)";
+    }
+    return rc;
+  };
+  if (iterate < 1) return give_up(fail(SODA_HIP_ERR_CONSTRAINT, "iterate must be >= 1"));
+  if (slab->order != SODA_HIP_SLAB_SERIAL && slab->order != SODA_HIP_SLAB_BANDS_FIRST)
+    return give_up(fail(SODA_HIP_ERR_CONSTRAINT, "slab order %d", (int)slab->order));
+  SlabGeometry g;
+  int rc = slab_geometry(plan, slab, &g);
+  if (rc) return give_up(rc);
+  const soda_hip_program& p = plan->prog;
+  const int last = p.dim - 1;
   hipStream_t s = as_stream(stream);
   int64_t local_dims[SODA_HIP_MAX_DIMS] = {1, 1, 1, 1};
   for (int d = 0; d < p.dim; ++d) local_dims[d] = slab->dims[d];
   local_dims[last] = g.extent;
-  auto exchange_ghosts = [&](char* array) -> int {
+  const int64_t send_down = g.has_lo ? (int64_t)slab->exchange * slab->reach_hi : 0;
+  const int64_t send_up = g.has_hi ? (int64_t)slab->exchange * slab->reach_lo : 0;
+  auto exchange_ghosts = [&](char* array, hipStream_t on) -> int {
     if (slab->world == 1) return 0;
     const Rccl& r = rccl();
-    const int64_t send_down = g.has_lo ? (int64_t)slab->exchange * slab->reach_hi : 0;
-    const int64_t send_up = g.has_hi ? (int64_t)slab->exchange * slab->reach_lo : 0;
     char* first_own = array + g.ghost_lo * g.row_bytes;
     char* last_own = first_own + g.own * g.row_bytes;
     int e = r.group_start();
     // lower neighbour: it needs our first rows, we need its last ones
     if (!e && g.has_lo && send_down)
-      e = r.send(first_own, (size_t)(send_down * g.row_bytes), 0, slab->rank - 1, comm, s);
+      e = r.send(first_own, (size_t)(send_down * g.row_bytes), 0, slab->rank - 1, comm, on);
     if (!e && g.has_lo && g.ghost_lo)
-      e = r.recv(array, (size_t)(g.ghost_lo * g.row_bytes), 0, slab->rank - 1, comm, s);
+      e = r.recv(array, (size_t)(g.ghost_lo * g.row_bytes), 0, slab->rank - 1, comm, on);
     if (!e && g.has_hi && send_up)
       e = r.send(last_own - send_up * g.row_bytes, (size_t)(send_up * g.row_bytes), 0,
-                 slab->rank + 1, comm, s);
+                 slab->rank + 1, comm, on);
     if (!e && g.has_hi && g.ghost_hi)
-      e = r.recv(last_own, (size_t)(g.ghost_hi * g.row_bytes), 0, slab->rank + 1, comm, s);
+      e = r.recv(last_own, (size_t)(g.ghost_hi * g.row_bytes), 0, slab->rank + 1, comm, on);
     const int e2 = r.group_end();
     if (e || e2)
       return fail(SODA_HIP_ERR_DEVICE_RUN, "RCCL ghost exchange failed: %s",
                   r.error_string ? r.error_string(e ? e : e2) : "?");
     return 0;
   };
+  // Bands-first order (runtime/dist.py: run_slab with a StreamSchedule, the same
+  // band_plan): every super-step but the last first sweeps the two bands of rows its
+  // neighbours are waiting for, hands them to the exchange of the NEXT super-step on a
+  // stream the plan owns, and sweeps the interior meanwhile.  A piece's intermediate
+  // launches must not write rows of `dst` another piece has finished (they are being
+  // sent): pieces run with out_final_only.
+  const bool overlapped = slab->order == SODA_HIP_SLAB_BANDS_FIRST && slab->world > 1;
+  if (overlapped && !plan->side) {
+    if (hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&plan->ev_main, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&plan->ev_landed, hipEventDisableTiming) != hipSuccess)
+      return give_up(fail(SODA_HIP_ERR_DEVICE_RUN, "side stream for the exchange: %s",
+                          hipGetErrorString(hipGetLastError())));
+  }
+  bool landed_pending = false;      // an exchange on the side stream main has not waited for
+  auto exchange = [&](char* array) -> int {
+    if (!overlapped) return exchange_ghosts(array, s);
+    // the rows to be sent were produced on the main stream: the side stream follows
+    // everything enqueued there so far
+    if (hipEventRecord(plan->ev_main, s) != hipSuccess ||
+        hipStreamWaitEvent(plan->side, plan->ev_main, 0) != hipSuccess)
+      return fail(SODA_HIP_ERR_DEVICE_RUN, "ordering the exchange stream failed");
+    int e = exchange_ghosts(array, plan->side);
+    if (e) return e;
+    if (hipEventRecord(plan->ev_landed, plan->side) != hipSuccess)
+      return fail(SODA_HIP_ERR_DEVICE_RUN, "hipEventRecord failed");
+    landed_pending = true;
+    return 0;
+  };
+  auto ghosts_have_landed = [&]() -> int {      // before a sweep reads ghost rows
+    if (!landed_pending) return 0;
+    landed_pending = false;
+    if (hipStreamWaitEvent(s, plan->ev_landed, 0) != hipSuccess)
+      return fail(SODA_HIP_ERR_DEVICE_RUN, "hipStreamWaitEvent failed");
+    return 0;
+  };
+  const bool was_final_only = plan->out_final_only;
+  // test hook (SODA_HIP_TUNING=1 only): rank R fails at its K-th super-step
+  int fail_rank = -1, fail_at = -1;
+  if (const char* env = tuning_env("SODA_HIP_FAIL_RANK")) fail_rank = atoi(env);
+  if (const char* env = tuning_env("SODA_HIP_FAIL_SUPERSTEP")) fail_at = atoi(env);
   void* src = a;
   void* cycle[2] = {b, c};
   int done = 0, k = 0, count = 0;
-  while (done < iterate) {
-    if ((rc = exchange_ghosts((char*)src))) return rc;
-    count += slab->world > 1;
+  bool pending = false;            // src's ghost rows are (being) filled already
+  while (done < iterate && !rc) {
+    if (!pending) {
+      rc = exchange((char*)src);
+      count += slab->world > 1;
+    }
+    if (!rc) rc = ghosts_have_landed();
+    if (rc) break;
+    pending = false;
     const int step = std::min(slab->exchange, iterate - done);
     // valid region of the slab's input: ghost sides are fully valid, the global
     // sides carry the margin of the iterations done so far
@@ -1570,11 +1777,58 @@ int soda_hip_run_slab(soda_hip_plan* plan, const soda_hip_slab* slab, void* comm
     if (g.has_lo) lo[last] = 0;
     if (g.has_hi) hi[last] = 0;
     void* dst = cycle[k % 2];
-    if ((rc = soda_hip_sweep(plan, &src, &dst, local_dims, step, lo, hi, stream))) return rc;
+    if (slab->rank == fail_rank && k == fail_at) {
+      rc = fail(SODA_HIP_ERR_DEVICE_RUN, "injected failure of rank %d at super-step %d",
+                fail_rank, fail_at);
+      break;
+    }
+    const bool more = done + step < iterate;
+    const bool small = g.own < 2 * (send_down + send_up) + 1;
+    if (overlapped && more && !small) {
+      const int64_t first_own = g.ghost_lo, last_own = g.ghost_lo + g.own;
+      const int64_t reach_lo = (int64_t)step * slab->reach_lo,
+                    reach_hi = (int64_t)step * slab->reach_hi;
+      auto piece = [&](int64_t r0, int64_t r1, bool cut_lo, bool cut_hi) -> int {
+        int32_t plo[SODA_HIP_MAX_DIMS], phi[SODA_HIP_MAX_DIMS];
+        for (int d = 0; d < SODA_HIP_MAX_DIMS; ++d) { plo[d] = lo[d]; phi[d] = hi[d]; }
+        if (cut_lo) plo[last] = 0;
+        if (cut_hi) phi[last] = 0;
+        int64_t dims_piece[SODA_HIP_MAX_DIMS];
+        for (int d = 0; d < SODA_HIP_MAX_DIMS; ++d) dims_piece[d] = local_dims[d];
+        dims_piece[last] = r1 - r0;
+        void* sp = (char*)src + r0 * g.row_bytes;
+        void* dp = (char*)dst + r0 * g.row_bytes;
+        plan->out_final_only = true;
+        const int e = soda_hip_sweep(plan, &sp, &dp, dims_piece, step, plo, phi, stream);
+        plan->out_final_only = was_final_only;
+        return e;
+      };
+      int64_t lo_edge = first_own, hi_edge = last_own;
+      if (g.has_lo) {    // the lower neighbour's ghost rows: our first send_down rows
+        rc = piece(first_own - reach_lo, first_own + send_down + reach_hi, true, true);
+        lo_edge = first_own + send_down;
+      }
+      if (!rc && g.has_hi) {
+        rc = piece(last_own - send_up - reach_lo, last_own + reach_hi, true, true);
+        hi_edge = last_own - send_up;
+      }
+      if (!rc) {
+        rc = exchange((char*)dst);        // beside the interior sweep
+        count += 1;
+        pending = true;
+      }
+      if (!rc)
+        rc = piece(g.has_lo ? lo_edge - reach_lo : 0,
+                   g.has_hi ? hi_edge + reach_hi : g.extent, g.has_lo, g.has_hi);
+    } else {
+      rc = soda_hip_sweep(plan, &src, &dst, local_dims, step, lo, hi, stream);
+    }
     src = dst;
     done += step;
     ++k;
   }
+  if (!rc) rc = ghosts_have_landed();
+  if (rc) return give_up(rc);
   *result = src;
   if (exchanges) *exchanges = count;
   return 0;

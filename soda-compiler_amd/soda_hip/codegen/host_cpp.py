@@ -242,6 +242,10 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
   w('      // never deeper than the smallest slab (all ranks compute the same value)\n')
   w('      rc = soda_hip_slab_exchange(rows, ngpu, lo[last], hi[last], exchange, &exchange);\n')
   w('      slab.exchange = ngpu > 1 ? exchange : iterate;\n')
+  # the order of exchange and sweeps: serial unless the environment asks for the
+  # bands-first order (include/soda_hip.h: SODA_HIP_SLAB_BANDS_FIRST)
+  w('      slab.order = getenv("SODA_HIP_SLAB_BANDS_FIRST") ? SODA_HIP_SLAB_BANDS_FIRST : '
+    'SODA_HIP_SLAB_SERIAL;\n')
   w('      if (!rc) rc = soda_hip_slab_extent(plan, &slab, local, &ghost_lo, &ghost_hi);\n')
   w('      row_bytes = (size_t)in->elem_size;\n')
   w('      for (int d = 0; d < last; ++d) row_bytes *= (size_t)in->extent[d];\n')
@@ -265,6 +269,9 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
   w('    if (go) {\n')
   w('      rc = soda_hip_run_slab(plan, &slab, comms[rank], a, b, c, iterate, '
     'nullptr, &result, nullptr);\n')
+  w('      if (rc && ngpu > 1) {\n')
+  w('        // soda_hip_run_slab has aborted this rank\'s communicator before returning\n')
+  w('        std::lock_guard<std::mutex> lock(gate);\n        comms[rank] = nullptr;\n      }\n')
   w('      if (!rc) rc = soda_hip_stream_synchronize(nullptr);\n')
   w('      if (rc) {\n')
   w('        fprintf(*error_report, "ERROR: GPU %d: %s: %s\\n", rank, '

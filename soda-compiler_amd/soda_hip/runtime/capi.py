@@ -11,7 +11,7 @@ MAX_TENSORS = 16
 MAX_IO = 8
 MAX_WINDOWS = 64
 MAX_KERNELS = 32
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 KERNEL_STAGE = 0
 KERNEL_FUSED = 1
@@ -57,7 +57,11 @@ class Slab(ctypes.Structure):
               ('reach_lo', ctypes.c_int32), ('reach_hi', ctypes.c_int32),
               ('exchange', ctypes.c_int32),
               ('dims', ctypes.c_int64 * MAX_DIMS),
-              ('own_first', ctypes.c_int64), ('own_last', ctypes.c_int64)]
+              ('own_first', ctypes.c_int64), ('own_last', ctypes.c_int64),
+              ('order', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+SLAB_SERIAL, SLAB_BANDS_FIRST = 0, 1
 
 
 class Timing(ctypes.Structure):
@@ -130,6 +134,9 @@ SIGNATURES = {
     'soda_hip_sweep_timed': (ctypes.c_int, [_VP, _VPP, _VPP, _I64P, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, _VP,
                                             ctypes.POINTER(Timing)]),
+    'soda_hip_clock_probe_start': (ctypes.c_int, [_VP, ctypes.c_int]),
+    'soda_hip_clock_probe_finish': (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_double),
+                                                   ctypes.POINTER(ctypes.c_double)]),
     'soda_hip_slab_exchange': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int,
                                               ctypes.POINTER(ctypes.c_int)]),

@@ -321,6 +321,22 @@ class Program:
                 dominant_us=t.dominant_us, dominant_launches=t.dominant_launches,
                 dominant_name=t.dominant_name.decode(), fastest_us=t.fastest_us)
 
+  def shader_clock_during(self, work, seconds):
+    """GHz the shader clock holds while `work()` (a callable that enqueues about
+    `seconds` of sweeps and returns without waiting) runs: one probe wavefront sleeps
+    beside it for ~60 % of that time (soda_hip_clock_probe_start / _finish).  None for
+    blobs without the probe kernel."""
+    spins = max(4, int(seconds * 0.6 / 3.9e-6))
+    try:
+      capi.check(capi.lib().soda_hip_clock_probe_start(self.handle, spins))
+    except capi.SodaHipError:
+      return None
+    work()
+    ghz, took = ctypes.c_double(), ctypes.c_double()
+    capi.check(capi.lib().soda_hip_clock_probe_finish(self.handle, ctypes.byref(ghz),
+                                                      ctypes.byref(took)))
+    return dict(ghz=ghz.value, seconds=took.value)
+
   # -- numpy conveniences (tests, <app>_test) --------------------------------
   def run_numpy(self, inputs, iterate=None, timed=False):
     """inputs: C-ordered arrays of shape reversed(dims).  Returns the output

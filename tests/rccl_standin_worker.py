@@ -19,6 +19,8 @@ for p in (ROOT, os.path.join(ROOT, 'soda-compiler_amd')):
 
 def main():
   standin_path, app, size, world, iterate, wanted, out_dir = sys.argv[1:8]
+  order = int(sys.argv[8]) if len(sys.argv) > 8 else 0      # capi.SLAB_BANDS_FIRST = 1
+  expect_failure = len(sys.argv) > 9 and sys.argv[9] == 'expect-failure'
   dims = [int(v) for v in size.split('x')]
   world, iterate, wanted = int(world), int(iterate), int(wanted)
   standin = ctypes.CDLL(standin_path, mode=ctypes.RTLD_GLOBAL)
@@ -56,6 +58,7 @@ def main():
       slab.rank, slab.world = rank, world
       slab.reach_lo, slab.reach_hi = r_lo, r_hi
       slab.exchange = exchange.value
+      slab.order = order
       for d, n in enumerate(dims):
         slab.dims[d] = n
       slab.own_first = rank * base + min(rank, extra)
@@ -75,9 +78,16 @@ def main():
       arrays[2].zero()
       capi.check(lib.soda_hip_stream_synchronize(None))
       result, count = ctypes.c_void_p(), ctypes.c_int()
-      capi.check(lib.soda_hip_run_slab(
+      rc = lib.soda_hip_run_slab(
           prog.handle, ctypes.byref(slab), comms[rank], arrays[0].ptr, arrays[1].ptr,
-          arrays[2].ptr, iterate, stream, ctypes.byref(result), ctypes.byref(count)))
+          arrays[2].ptr, iterate, stream, ctypes.byref(result), ctypes.byref(count))
+      if rc:
+        # an error return means the library has aborted this rank's communicator already
+        # (include/soda_hip.h): it must not be aborted or destroyed again
+        comms[rank] = None
+        message = lib.soda_hip_last_error().decode()
+        lib.soda_hip_stream_synchronize(stream)
+        raise RuntimeError('soda_hip_run_slab: %d %s' % (rc, message))
       capi.check(lib.soda_hip_stream_synchronize(stream))
       which = [a for a in arrays if a.ptr == result.value][0]
       out = which.download(local_shape, dt)
@@ -86,9 +96,11 @@ def main():
       prog.close()
     except BaseException as e:   # noqa: BLE001 - reported by the parent
       errors[rank] = e
-      # peers blocked in the exchange must not hang: abort the group
-      standin.ncclCommAbort(ctypes.c_void_p(comms[rank]))
-      comms[rank] = None
+      # peers blocked in the exchange must not hang: abort the group (unless
+      # soda_hip_run_slab did so itself)
+      if comms[rank]:
+        standin.ncclCommAbort(ctypes.c_void_p(comms[rank]))
+        comms[rank] = None
 
   threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
   for t in threads:
@@ -101,6 +113,16 @@ def main():
   for rank, e in enumerate(errors):
     if e is not None:
       print('rank %d: %r' % (rank, e), file=sys.stderr)
+  if expect_failure:
+    # a rank was made to fail (SODA_HIP_FAIL_RANK): EVERY rank must have come back with
+    # an error - nobody hangs, nobody reports success on stale ghost rows
+    with open(os.path.join(out_dir, 'errors.txt'), 'w') as f:
+      for rank, e in enumerate(errors):
+        f.write('%d %s\n' % (rank, 'ok' if e is None else str(e).replace('\n', ' ')))
+    for c in comms:
+      if c:
+        standin.ncclCommDestroy(ctypes.c_void_p(c))
+    sys.exit(0)
   if any(e is not None for e in errors):
     sys.exit(2)
   messages, nbytes = ctypes.c_longlong(), ctypes.c_longlong()

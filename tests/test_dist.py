@@ -84,6 +84,11 @@ def run_world(tmp_path, world, app, dims, iterate, exchange, overlap=False):
     (3, 'blur', (60, 110), 9, 6, 2),
     # slabs too thin to cut bands from (10 own rows, 3 + 3 to send)
     (3, 'jacobi2d', (48, 30), 8, 3, True),
+    # BASELINE cfg5's shape in small: planes cut into slabs THINNER than the iteration
+    # count, so the edge ranks run out of valid cells (their boxes are empty for the last
+    # super-steps) while the middle ranks still need their rows - nobody may stall
+    (4, 'jacobi3d', (20, 18, 24), 8, 2, False),
+    (4, 'jacobi3d', (26, 24, 32), 10, 4, True),
 ])
 def test_slabs_match_single_process(tmp_path, world, app, dims, iterate, exchange,
                                     overlap):

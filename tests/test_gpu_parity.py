@@ -867,6 +867,75 @@ def test_per_stage_kernels_beyond_the_grid_limit():
   assert np.array_equal(staged[1:-1, 1:-1, 1:-1], want[1:-1, 1:-1, 1:-1])
 
 
+def test_clock_probe_reports_the_shader_clock_under_load():
+  """soda_hip_clock_probe_start / _finish: one wavefront sleeps beside the sweeps and
+  counts shader cycles against the constant 100 MHz clock - what bench.py prints as
+  roofline.shader_clock_ghz.  MI355X: at most 2.4 GHz; a loaded chip holds 1.9-2.4."""
+  from soda_hip.runtime import host
+  prog = program('jacobi2d')
+  dims = [8192, 4096]
+  a = np.random.default_rng(3).random((4096, 8192), dtype=np.float32)
+  din = host.DeviceArray(a.nbytes)
+  din.upload(a)
+  dout = host.DeviceArray(a.nbytes)
+  dout.zero()
+  prog.set_max_depth(0)
+  prog.sweep([din.ptr], [dout.ptr], dims, 48)          # scratch, clocks
+  got = prog.shader_clock_during(
+      lambda: [prog.sweep([din.ptr], [dout.ptr], dims, 48) for _ in range(20)], 0.02)
+  host.capi.check(host.capi.lib().soda_hip_stream_synchronize(None))
+  assert got is not None and 0.005 < got['seconds'] < 0.2
+  assert 1.0 < got['ghz'] <= 2.45, got
+  # one probe at a time, and _finish needs a _start
+  import ctypes
+  lib = host.capi.lib()
+  assert lib.soda_hip_clock_probe_finish(prog.handle, ctypes.byref(ctypes.c_double()),
+                                         None) != 0
+  assert lib.soda_hip_clock_probe_start(prog.handle, 10) == 0
+  assert lib.soda_hip_clock_probe_start(prog.handle, 10) != 0
+  ghz = ctypes.c_double()
+  assert lib.soda_hip_clock_probe_finish(prog.handle, ctypes.byref(ghz), None) == 0
+  din.free()
+  dout.free()
+
+
+def test_tuning_the_streaming_launches_changes_speed_only():
+  """soda_hip_plan_tune also times the chunk length x workgroup cap of memory-bound
+  launches beyond the Infinity Cache against its neighbours (the calibrated pair was
+  measured on one box): whatever it keeps, the sweep's results stay the oracle's, for a
+  one-launch sweep (blur) and for one whose last launch streams (jacobi2d x 25)."""
+  from soda_hip.runtime import host
+  for app, dims, iterate in (('blur', [16384, 10240], 1), ('jacobi2d', [12288, 8192], 25)):
+    prog = gpu_util.open_prebuilt(app)
+    try:
+      spec = gpu_util.load_spec(app, iterate=iterate)
+      dt = prog.in_dtypes[0]
+      rng = np.random.default_rng(31)
+      shape = tuple(reversed(dims))
+      a = rng.random(shape, dtype=np.float32) if dt.kind == 'f' else \
+          rng.integers(0, 65536, size=shape).astype(dt)
+      din = host.DeviceArray(a.nbytes)
+      din.upload(a)
+      dout = host.DeviceArray(a.nbytes)
+      dout.zero()
+      before = [e['name'] for e, _ in prog.schedule(dims, iterate)]
+      prog.tune([din.ptr], [dout.ptr], dims, iterate)
+      # (the split of iterate may change; every launch is still a kernel of the blob)
+      assert sum(max(1, e['depth']) for e, _ in prog.schedule(dims, iterate)) == iterate
+      assert before
+      dout.zero()
+      prog.sweep([din.ptr], [dout.ptr], dims, iterate)
+      got = dout.download(a.shape, a.dtype)
+      orc = gpu_util.make_oracle(gpu_util.load_spec(app))
+      want = orc.run([a], iterate=iterate)[spec['outputs'][0]]
+      sl = orc.valid_slices(tuple(dims), iterate)
+      assert want[sl].size > 0 and np.array_equal(got[sl], want[sl])
+      din.free()
+      dout.free()
+    finally:
+      prog.close()
+
+
 def test_tall_narrow_streaming_box_beyond_the_grid_limit():
   """A streaming launch beyond the Infinity Cache walks the kernel's MEASURED chunk
   (soda_hip_kernel.stream_chunk: 8-32 rows), and 600 000 rows in chunks of 8 would be
@@ -1245,15 +1314,24 @@ def build_rccl_standin(tmp_path):
   return out
 
 
-@pytest.mark.parametrize('app,dims,world,iterate,exchange', [
-    ('jacobi2d', (1300, 900), 2, 70, 24),
-    ('jacobi2d', (700, 1500), 3, 100, 60),     # three launches per super-step
-    ('skew2d', (900, 800), 3, 30, 8),          # ghost regions 2 rows deep per iteration
+@pytest.mark.parametrize('app,dims,world,iterate,exchange,order', [
+    ('jacobi2d', (1300, 900), 2, 70, 24, 0),
+    ('jacobi2d', (700, 1500), 3, 100, 60, 0),  # three launches per super-step
+    ('skew2d', (900, 800), 3, 30, 8, 0),       # ghost regions 2 rows deep per iteration
                                                # on one side, 1 on the other
-    ('jacobi3d', (130, 70, 200), 2, 20, 8),
-    ('jacobi3d', (140, 150, 90), 3, 9, 100)])  # period clamped to the smallest slab
+    ('jacobi3d', (130, 70, 200), 2, 20, 8, 0),
+    ('jacobi3d', (140, 150, 90), 3, 9, 100, 0),   # period clamped to the smallest slab
+    # bands first, exchange on the plan's second stream beside the interior sweep
+    # (SODA_HIP_SLAB_BANDS_FIRST): super-steps of three and more launches, whose
+    # intermediate launches must not touch rows that are being sent
+    ('jacobi2d', (700, 1500), 3, 200, 60, 1),
+    ('jacobi2d', (1300, 2400), 2, 130, 44, 1),
+    ('skew2d', (900, 1200), 3, 50, 12, 1),
+    ('jacobi3d', (130, 70, 200), 2, 20, 8, 1),
+    ('jacobi2d', (600, 900), 3, 250, 100, 1)])  # slabs too thin for bands: whole sweeps
 def test_run_slab_with_two_and_three_ranks_over_the_rccl_standin(tmp_path, app, dims,
-                                                                 world, iterate, exchange):
+                                                                 world, iterate, exchange,
+                                                                 order):
   """soda_hip_run_slab - the C slab driver: ncclSend / ncclRecv inside one group per
   super-step on the caller's stream, then the sweep - with world > 1.  RCCL refuses two
   ranks on one GPU and this box has one, so the ranks are host threads over a
@@ -1268,7 +1346,7 @@ def test_run_slab_with_two_and_three_ranks_over_the_rccl_standin(tmp_path, app, 
   r = subprocess.run(
       [sys.executable, os.path.join(ROOT, 'tests', 'rccl_standin_worker.py'), standin,
        app, 'x'.join(map(str, dims)), str(world), str(iterate), str(exchange),
-       str(tmp_path)], capture_output=True, text=True, timeout=600)
+       str(tmp_path), str(order)], capture_output=True, text=True, timeout=600)
   assert r.returncode == 0, r.stderr[-2000:]
   spec = gpu_util.load_spec(app, iterate=iterate)
   dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
@@ -1291,6 +1369,34 @@ def test_run_slab_with_two_and_three_ranks_over_the_rccl_standin(tmp_path, app, 
   # (a one-sided window sends nothing one way)
   assert messages == count * (world - 1) * ((r_lo > 0) + (r_hi > 0))
   assert nbytes == count * (world - 1) * period * (r_lo + r_hi) * row_bytes
+
+
+@pytest.mark.parametrize('order,fail_rank,fail_at', [(0, 1, 1), (1, 0, 1), (1, 2, 0)])
+def test_a_rank_that_fails_mid_run_does_not_leave_its_peers_blocked(tmp_path, order,
+                                                                    fail_rank, fail_at):
+  """soda_hip_run_slab aborts the communicator before it returns an error (a failed
+  launch, allocation or exchange), so the neighbours' ncclRecv fail instead of waiting for
+  rows that will never come: with one rank made to fail at a given super-step
+  (SODA_HIP_FAIL_RANK / _SUPERSTEP, a test hook behind SODA_HIP_TUNING) every rank of a
+  three-rank group returns an error within the time limit, in both orders."""
+  import subprocess
+  import sys
+  from conftest import ROOT
+  standin = build_rccl_standin(tmp_path)
+  r = subprocess.run(
+      [sys.executable, os.path.join(ROOT, 'tests', 'rccl_standin_worker.py'), standin,
+       'jacobi2d', '700x1500', '3', '200', '48', str(tmp_path), str(order),
+       'expect-failure'], capture_output=True, text=True, timeout=240,
+      env=dict(os.environ, SODA_HIP_TUNING='1', SODA_HIP_FAIL_RANK=str(fail_rank),
+               SODA_HIP_FAIL_SUPERSTEP=str(fail_at)))
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = open(os.path.join(tmp_path, 'errors.txt')).read().splitlines()
+  assert len(lines) == 3
+  for rank, text in enumerate(lines):
+    assert text.split()[0] == str(rank) and 'soda_hip_run_slab' in text, lines
+    assert 'communicator aborted' in text, lines
+  assert 'injected failure of rank %d at super-step %d' % (fail_rank, fail_at) in \
+      lines[fail_rank]
 
 
 def test_bench_py_as_the_driver_launches_it_for_two_gpus():
@@ -1351,6 +1457,49 @@ def test_bench_py_as_the_driver_launches_it_for_two_gpus():
   cpu = d['cpu_baseline']
   assert cpu['kind'] == 'port' and cpu['value'] > 0 and len(cpu['samples']) == 3
   assert c['super_step_schedule']
+
+
+def test_bench_py_for_the_three_dimensional_multi_gpu_config():
+  """BASELINE cfg5 is an 8-GPU config (jacobi3d 512^3 x 200 in 64-plane slabs: the edge
+  ranks' own planes leave the valid box after 64 iterations while the middle ranks go
+  on).  The driver's command line for it, rehearsed on this box's ONE GPU with four gloo
+  ranks and the same proportions (160 x 160 x 192, 64 iterations, 48-plane slabs): the line, the candidate
+  table, the compute-only time, and nobody stalls on a rank whose boxes are empty."""
+  import socket
+  import subprocess
+  import sys
+  from conftest import ROOT
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  r = subprocess.run(
+      [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
+       '4', '--master-addr', '127.0.0.1', '--master-port', str(port),
+       os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '1', '--warmup', '0',
+       '--app', 'jacobi3d', '--size', '160', '160', '192', '--iterate', '64',
+       '--cpu-seconds', '0', '--no-tune'],
+      capture_output=True, text=True, timeout=900,
+      env=dict(os.environ, SODA_DIST_BACKEND='gloo', OMP_NUM_THREADS='2'))
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+  assert len(lines) == 1, r.stdout[-2000:]
+  d = json.loads(lines[0])
+  c = d['config']
+  assert d['n_gpus'] == 4 and c['dims'] == [160, 160, 192] and c['iterate'] == 64
+  assert c['parallelism'] == 'outer-dim slabs x4' and d['scaling'] == 'strong'
+  table = c['exchange_candidates_ms']
+  # periods 4, 8, 16, 32 (1, 2, 4, 8 x the deepest 3-D kernel), serial and overlapped
+  assert sorted({row['exchange'] for row in table}) == [4, 8, 16, 32]
+  assert len(table) == 8 and all(row['ms'] > 0 and row['repeats'] >= 3 for row in table)
+  assert (c['exchange_every'], c['exchange_overlapped']) in {
+      (row['exchange'], row['overlapped']) for row in table}
+  assert c['exchanges_per_step'] == -(-64 // c['exchange_every'])
+  assert 0 < c['compute_only_ms_per_step'] < 1.5 * d['ms_per_step']
+  from soda_hip.codegen import spec as specmod
+  valid = specmod.valid_cells(gpu_util.load_spec('jacobi3d', iterate=64), [160, 160, 192], 64)
+  assert abs(d['value'] - valid / (d['ms_per_step'] * 1e-3) / 1e9) < 1e-6 * d['value']
+  assert d['roofline']['kernel'].startswith('jacobi3d_fused_k')
 
 
 def test_bench_py_one_rank_group_over_real_rccl():

@@ -16,7 +16,8 @@ app = sys.argv[1]
 opts = {k: (int(v) if v.lstrip('-').isdigit() else v) for k, v in (kv.split('=') for kv in sys.argv[2].split(','))} if len(sys.argv) > 2 and sys.argv[2] else {}
 ok = True
 max_depth = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-cases = ((12, (300, 1100)), (25, (257, 1021)), (13, (100, 2049)), (37, (611, 700)), (8, (64, 64)))
+cases = ((12, (300, 1100)), (25, (257, 1021)), (13, (100, 2049)), (37, (611, 700)), (8, (64, 64)),
+         (16, (200, 3000)), (40, (150, 4100)), (28, (90, 1024)))
 if max_depth == 1:
   cases = ((1, (300, 1100)), (2, (257, 1021)), (3, (100, 2049)), (1, (611, 700)), (2, (64, 64)),
            (1, (70, 255)), (2, (33, 513)), (1, (9, 11)), (1, (40, 256)), (1, (1500, 768)),
