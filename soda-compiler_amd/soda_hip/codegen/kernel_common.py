@@ -198,24 +198,6 @@ DEV void soda_lds_read_pairs4(const void* p, soda_pk2& a, soda_pk2& b, soda_pk2&
                : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
                : "v"((unsigned)(unsigned long long)p) : "memory");
 }
-// ... and a lane's 16 consecutive floats as eight pairs {f[c], f[c+8]} (strips of 1024
-// columns, kernel_stream2d_wp wide_cols=8)
-DEV void soda_lds_read_pairs8(const void* p, soda_pk2& a, soda_pk2& b, soda_pk2& c,
-                              soda_pk2& d, soda_pk2& e, soda_pk2& f, soda_pk2& g,
-                              soda_pk2& h) {
-  asm volatile("ds_read2_b32 %%0, %%8 offset1:8\\n\\t"
-               "ds_read2_b32 %%1, %%8 offset0:1 offset1:9\\n\\t"
-               "ds_read2_b32 %%2, %%8 offset0:2 offset1:10\\n\\t"
-               "ds_read2_b32 %%3, %%8 offset0:3 offset1:11\\n\\t"
-               "ds_read2_b32 %%4, %%8 offset0:4 offset1:12\\n\\t"
-               "ds_read2_b32 %%5, %%8 offset0:5 offset1:13\\n\\t"
-               "ds_read2_b32 %%6, %%8 offset0:6 offset1:14\\n\\t"
-               "ds_read2_b32 %%7, %%8 offset0:7 offset1:15\\n\\t"
-               "s_waitcnt lgkmcnt(0)"
-               : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f), "=&v"(g),
-                 "=&v"(h)
-               : "v"((unsigned)(unsigned long long)p) : "memory");
-}
 DEV int lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
@@ -454,129 +436,3 @@ def cell_assignment(stage, target, load, emit, indent):
   emit('%s  %s = %s;' % (indent, target, value))
   emit(indent + '}')
 
-
-# ---------------------------------------------------------------------------
-# Splitting an expression into what can be computed EARLY and the rest
-# ---------------------------------------------------------------------------
-_SPLIT_TOKEN = re.compile(
-    r'\s*(\{[^}]*\}|(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?f?|[-+*/()])')
-PRE_MARK = '@PRE@'
-
-
-def _parse_plain(text):
-  """`text` (loads as placeholders, + - * /, literals, parentheses) as a tree:
-  ('atom', text) | ('neg', sign, node) | ('chain', [nodes], [ops]).  None if it holds
-  anything else."""
-  tokens, pos = [], 0
-  text = text.strip()
-  while pos < len(text):
-    m = _SPLIT_TOKEN.match(text, pos)
-    if not m:
-      return None
-    tokens.append(m.group(1))
-    pos = m.end()
-  at = [0]
-
-  def operand():
-    if at[0] >= len(tokens):
-      raise ValueError
-    tok = tokens[at[0]]
-    at[0] += 1
-    if tok == '(':
-      node = chain()
-      if at[0] >= len(tokens) or tokens[at[0]] != ')':
-        raise ValueError
-      at[0] += 1
-      return node
-    if tok in '+-':
-      return ('neg', tok, operand())
-    if tok in '*/)':
-      raise ValueError
-    return ('atom', tok)
-
-  def chain():
-    nodes, ops = [operand()], []
-    while at[0] < len(tokens) and tokens[at[0]] in '+-*/':
-      ops.append(tokens[at[0]])
-      at[0] += 1
-      nodes.append(operand())
-    return ('chain', nodes, ops) if ops else nodes[0]
-
-  try:
-    tree = chain()
-  except ValueError:
-    return None
-  return tree if at[0] == len(tokens) else None
-
-
-def _print_plain(node):
-  if node[0] == 'atom':
-    return node[1]
-  if node[0] == 'neg':
-    return '(%s%s)' % (node[1], _print_plain(node[2]))
-  parts = [_print_plain(node[1][0])]
-  for op, operand in zip(node[2], node[1][1:]):
-    parts += [op, _print_plain(operand)]
-  return '(%s)' % ' '.join(parts)
-
-
-def _atoms(node):
-  if node[0] == 'atom':
-    return [node[1]]
-  if node[0] == 'neg':
-    return _atoms(node[2])
-  return [a for n in node[1] for a in _atoms(n)]
-
-
-def split_early_prefix(text, is_late):
-  """Splits a plain float expression into (early, rest): `early` is a subexpression whose
-  loads all satisfy `not is_late(tensor, rel)`, `rest` the expression with PRE_MARK in its
-  place - evaluating `early` first and `rest` on its value performs the SAME operations in
-  the SAME order as the expression itself (a + b + c + d is ((a + b) + c) + d in C; the
-  prefix a + b of a chain of one operator class is one of its own intermediate values).
-  Walks down through first operands: ((a + b + NEW + c) * k) gives early = (a + b),
-  rest = ((@PRE@ + NEW + c) * k).  Returns (None, text) when nothing of two or more
-  operands can be taken, or the text holds more than loads, + - * /, literals and
-  parentheses.  The early part always holds a load, so it is float-typed whenever the
-  program's tensors are (integer literals alone would be integer arithmetic)."""
-  tree = _parse_plain(text)
-  if tree is None:
-    return None, text
-
-  def late(node):
-    for atom in _atoms(node):
-      m = specmod.LOAD_RE.fullmatch(atom)
-      if m and is_late(m.group(1), tuple(int(v) for v in m.group(2).split(','))):
-        return True
-    return False
-
-  def has_load(node):
-    return any(specmod.LOAD_RE.fullmatch(a) for a in _atoms(node))
-
-  def split(node):
-    """(early node, rest node) or None."""
-    if node[0] != 'chain':
-      return None
-    nodes, ops = node[1], node[2]
-    if not (all(o in '+-' for o in ops) or all(o in '*/' for o in ops)):
-      return None                  # mixed precedence at one level: not a left-to-right chain
-    k = 0
-    while k < len(nodes) and not late(nodes[k]):
-      k += 1
-    if k == len(nodes):
-      return None                  # (the caller takes the whole node)
-    if k >= 2 and has_load(('chain', nodes[:k], ops[:k - 1])):
-      early = ('chain', nodes[:k], ops[:k - 1])
-      return early, ('chain', [('atom', PRE_MARK)] + nodes[k:], ops[k - 1:])
-    if k == 1 and nodes[0][0] == 'chain' and has_load(nodes[0]):
-      return nodes[0], ('chain', [('atom', PRE_MARK)] + nodes[1:], ops)
-    if k == 0:
-      inner = split(nodes[0])
-      if inner:
-        return inner[0], ('chain', [inner[1]] + nodes[1:], ops)
-    return None
-
-  found = split(tree)
-  if not found:
-    return None, text
-  return _print_plain(found[0]), _print_plain(found[1])

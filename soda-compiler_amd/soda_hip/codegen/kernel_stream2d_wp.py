@@ -163,17 +163,8 @@ def packable(spec):
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
          max_period=12, vgpr_budget=120, skip_fill=1, pairs=0, align='none',
-         ring=0, waves_per_eu=0, split=None, prio=None, wide_cols=0):
+         ring=0, waves_per_eu=0, split=None, prio=None):
   """Returns (text, kernel table entry).
-
-  wide_cols=8 (with pairs=2): the lane holds SIXTEEN consecutive columns - eight register
-  pairs {column c, column c + 8} per level-row - and a wavefront streams one strip of 1024
-  columns.  Against the 512-column strip: the two lane-crossing scalar adds are paid per
-  16 cells instead of per 8 (42 instructions per level-row of 16 cells against 2 x 22) and
-  the x halo per 1024 columns instead of per 512; a level costs 48 VGPRs instead of 24, so
-  it serves the shallower depths (12, 16: fewer fill rows per chunk), where short grids -
-  cfg2, the slabs of a 4- or 8-rank run - lose most to the fill.  The kernel is named
-  <app>_fused_k<depth>w and ships NEXT to the 512-column kernel of its depth.
 
   pairs=2 (needs the ring): ONE strip of 2 x 64 x C columns per wavefront; a
   lane holds 2C consecutive columns, the first C in the low halves of its pairs
@@ -214,10 +205,6 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   if cols is None:
     cols = max(1, 16 // elem)
   C = cols
-  if wide_cols:
-    if int(pairs) != 2 or wide_cols * elem != 32:
-      raise NotFusable('wide_cols: pairs=2 and 32-byte half-lanes')
-    C = int(wide_cols)
   if pairs and not packable(spec):
     raise NotFusable('packed form: float programs of + - * / only')
   if pairs and (C * elem) % 16:
@@ -228,7 +215,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
     raise NotFusable('2-D programs only')
   RS = int(ring)
   PF = RS - 2
-  if RS and (RS < 3 or (C * elem != 16 and not (wide and C * elem == 32))):
+  if RS and (RS < 3 or C * elem != 16):
     raise NotFusable('input ring: >= 3 slots, 16-byte lanes')
   if wide and not RS:
     raise NotFusable('wide strips come through the input ring')
@@ -242,9 +229,6 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   if wide:      # the second half adds 64 x C columns, all of them output
     geo['w_out'] += LANES * C
   strip_cols = LANES * C * (2 if wide else 1)
-  # LDS-direct loads of one input row: one 1 KiB piece (16 bytes per lane) each
-  ring_pieces = strip_cols * elem // (LANES * 16) if wide else P
-  piece_elems = 16 // elem
   for inst in everything:
     for src, rel, _ in inst.reads:
       if abs(rel[0]) > C:
@@ -290,7 +274,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
       below[id(src)] = max(below.get(id(src), -10**9), need - rel[1])
   for inst in everything:
     inst.first_step = max(0, inst.lag + geo['y_lo'] - below.get(id(inst), 0))
-  name = kernel_name(spec, depth) + ('w' if wide_cols else '')
+  name = kernel_name(spec, depth)
   L = final.lag
   T_in = builtin_type(in_type)
   T_out = builtin_type(types[out_name])
@@ -340,12 +324,12 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
 
   def ring_issue(row_expr, slot_index):
     line('        { i64 row = %s; if (row > H - 1) row = H - 1;' % row_expr)
-    for h in range(ring_pieces):
+    for h in range(P):
       line('          __builtin_amdgcn_global_load_lds((const __attribute__(('
            'address_space(1))) void*)(g_in + row * W + %s), (__attribute__(('
            'address_space(3))) void*)&in_ring[%d][%d][0], 16, 0, %d);'
-           % (('x - lane * %d + %d' % (2 * C - piece_elems, h * LANES * piece_elems))
-              if wide else ('xb' if h else 'x'), slot_index, h, 0))
+           % (('x - lane * %d + %d' % (C, h * LANES * C)) if wide else
+              ('xb' if h else 'x'), slot_index, h, 0))
     line('        }')
 
   def emit_body(mine, guarded):
@@ -357,12 +341,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
           ring_issue('head + %d' % (u + PF), (u + PF) % RS)
           # row head+u was issued PF rows ago
           line('        __builtin_amdgcn_s_waitcnt(%d);  // vmcnt(%d)'
-               % (vmcnt(PF * ring_pieces), PF * ring_pieces))
-          if wide and C == 8:
-            line('        soda_lds_read_pairs8(&in_ring[%d][0][0] + lane * 16, %s);'
-                 % (u % RS, ', '.join('%s[%d][%d]' % (inst.ident, s, c)
-                                      for c in range(C))))
-            continue
+               % (vmcnt(PF * P), PF * P))
           if wide and C == 4:
             # the four pairs straight from the LDS read (ds_read2_b32) instead of
             # two ds_read_b128 and eight register moves: 0.4-0.7 % per depth-16
@@ -480,9 +459,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   line('DEV void %s_strip(const soda_hip_args& a, const i64 xs, const i64 x, '
        'const i64 xb, const i64 y0, const i64 y1, const int wave, const int lane,'
        % name)
-  ring_dims = ((ring_pieces, LANES * piece_elems) if wide else (P, LANES * C)) if RS else (1, 1)
-  if RS and PF * ring_pieces > 63:
-    raise NotFusable('%d loads in flight exceed the vmcnt range' % (PF * ring_pieces))
+  ring_dims = (P, LANES * C) if RS else (1, 1)
   if pairs:
     line('    float (*handoff)[2][%d][%d][%d], %s (*in_ring)[%d][%d]) {'
          % (S, pieces, LANES * 4, T_in, ring_dims[0], ring_dims[1]))
@@ -612,6 +589,4 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
                origin_align=geo['origin_align'],
                fill_rows=L + geo['y_lo'], cols=C, prefetch=prefetch, period=period,
                est_vgprs=est_vgprs, groups=groups, w_out=geo['w_out'])
-  if wide_cols:
-    entry['wide_cols'] = int(wide_cols)
   return '\n'.join(o) + '\n', entry

@@ -96,7 +96,7 @@ ALIGN_OUT = 16      # cells: output tiles start and end on 64-byte pieces
 
 def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
          vgpr_budget=250, ring=0, pairs=0, stamps=0, mask_loads=0, nt=0,
-         wide_stores=0, lean_fill=0, prio=0, early=0):
+         wide_stores=0, lean_fill=0):
   """Returns (text, kernel table entry).
 
   `prefetch` = input planes loaded ahead into REGISTERS (R*C VGPRs each);
@@ -155,20 +155,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   stores every step (stores of skipped planes are dropped by the record count as always)
   - and a skipped level's edge rows are read only by cells that are skipped or unneeded
   themselves.  Round 3 measured level skipping with the branches in EVERY step: +14 %.
-  `early` = 1 (ring form, plain float programs): what bounds a step of this kernel outside
-  its arithmetic is the chain publish -> barrier -> LDS reads that ALL wavefronts of the
-  workgroup walk at the same time (stamps: input plane 470-500 + barrier 440-500 of 4 200
-  cycles; more wavefronts of the same workgroup do not hide it - profiles/r05_3d_
-  decomposition.txt).  So the step is cut where the data allows: every level's expression
-  is split (kernel_common.split_early_prefix) into the part that reads only planes of
-  EARLIER steps - for a 7-point level the five in-plane terms, four of its six adds - and
-  the rest; for the rows whose in-plane neighbours lie inside the band the early part needs
-  nothing from other wavefronts and is computed BEFORE the barrier, into the level's own
-  window slot, right after the previous step's publishes and while the input plane's ring
-  reads (issued first, waited for last) are in flight.  After the barrier a level finishes
-  those rows (its slot + the plane its parent just produced + the oldest plane, times the
-  constant: same operations in the same order) and computes the band's edge rows whole.
-  The last level has no slot to keep partial results in and stays whole.
   `stamps` = device address of a debug buffer (tools/blk_stamps.py only): the
   wavefront sums the shader cycles (s_memtime) it spends in each part of a step -
   input plane, each stage instance, the barrier - and lane 0 writes the sums there;
@@ -228,28 +214,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
       src.need_lo = lo_need if src.need_lo is None else max(src.need_lo, lo_need)
       src.need_hi = hi_need if src.need_hi is None else max(src.need_hi, hi_need)
   lean_fill = bool(lean_fill) and bool(ring) and not stamps
-  # `early`: see the docstring.  Per stage instance the part of its expression that reads
-  # only planes of EARLIER steps, and the band rows whose early part needs no edge row.
-  for inst in insts:
-    inst.pre = inst.rest = None
-    inst.pre_rows = []
-  if early and ring and not pairs and packable(spec):
-    for inst in insts[1:]:
-      if inst.final or inst.stage['lets']:      # (the last level has no window to wait in)
-        continue
-      by_name = {(n, tuple(rel)): src for src, rel, n in inst.reads}
-
-      def produced_this_step(tensor, rel, inst=inst, by_name=by_name):
-        src = by_name[(tensor, tuple(rel))]
-        return inst.lag - src.lag - rel[2] == 0
-      pre, rest = kernel_common.split_early_prefix(device_expr(inst.stage['expr']),
-                                                   produced_this_step)
-      if pre:
-        dys = [int(m.group(2).split(',')[1]) for m in specmod.LOAD_RE.finditer(pre)]
-        rows_ok = [r for r in range(R) if all(0 <= r + dy < R for dy in dys)]
-        if rows_ok:
-          inst.pre, inst.rest, inst.pre_rows = pre, rest, rows_ok
-  early = any(inst.pre for inst in insts)
   rows_per_load = 16 // (C * elem)     # a 16-byte-per-lane load covers this many rows
   if ring and (rows_per_load < 1 or R % rows_per_load):
     raise NotFusable('ring: %d rows per load do not divide %d rows' % (rows_per_load, R))
@@ -533,13 +497,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     line('  unsigned long long soda_prev = __builtin_readcyclecounter();')
 
   def stamp(k):
-    if prio == 3:
-      # the two wavefronts of a SIMD (bands w and w + G / 2) take turns at the higher issue
-      # priority, part by part: with equal (or fixed unequal) priorities one of them runs
-      # ahead, ends its step early and idles at the barrier while the other finishes alone
-      # at a single wavefront's issue rate
-      line('      if (wave < %d) __builtin_amdgcn_s_setprio(%d); else '
-           '__builtin_amdgcn_s_setprio(%d);' % (G // 2, 3 if k % 2 else 0, 0 if k % 2 else 3))
     if not stamps:
       # scheduling fence between the parts of a step: the input plane, each stage
       # instance, the barrier (what the stamped diagnostic build has as well)
@@ -641,127 +598,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     parts.append('n + %d < span + %d' % (u, last))
     return ' && '.join(parts), first, last
 
-  def emit_early(v, guarded, indent):
-    """The part of step v that needs nothing of step v - 1's neighbours: the input plane
-    out of the ring (issued, waited for after the arithmetic) and every level's early
-    partial results for the rows inside the band."""
-    s = slot(source, v, 0)
-    wait = (ring - 1) * ring_loads + ring * R
-    ragged_wait = (ring - 1) * ring_loads + ring * R * C
-    width = {4: 'b32', 8: 'b64', 16: 'b128'}[C * elem]
-    line(indent + '{  // early part of step %d' % v)
-    line(indent + '  __builtin_amdgcn_s_waitcnt(RAGGED ? %d : %d);  // vmcnt(%d / %d)' % (
-        vmcnt(min(63, ragged_wait)), vmcnt(wait), min(63, ragged_wait), wait))
-    line(indent + '  %s;' % '; '.join('%s rr%d' % (vec, r) for r in range(R)))
-    # (issued here, waited for below: the registers are outputs of the first asm and
-    # in-out operands of the second, nothing in between touches them)
-    line(indent + '  asm volatile(%s' % ''.join(
-        '"ds_read_%s %%%d, %%%d offset:%d\\n\\t"\n%s               ' % (
-            width, r, R, r * LANES * C * elem, indent) for r in range(R)).rstrip())
-    line(indent + '               : %s' % ', '.join('"=&v"(rr%d)' % r for r in range(R)))
-    line(indent + '               : "v"((unsigned)(unsigned long long)&in_ring[%d][wave][0]'
-         '[lane * %d]) : "memory");' % (v % ring, C))
-    line(indent + '  __builtin_amdgcn_sched_barrier(0);')
-    for inst in insts[1:]:
-      if not inst.pre:
-        continue
-      by_name = {(n, tuple(rel)): src for src, rel, n in inst.reads}
-      if guarded:
-        line(indent + '  if (%s) {' % needed(inst, v)[0])
-      for r in inst.pre_rows:
-        for c in range(C):
-          def load(tensor, rel, v=v, r=r, c=c, inst=inst, by_name=by_name):
-            return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), v, r, c)
-          line(indent + '  %s = %s;' % (cell(inst.ident, slot(inst, v, 0), r, c),
-                                       specmod.substitute_loads(inst.pre, load)))
-      if guarded:
-        line(indent + '  }')
-    line(indent + '  __builtin_amdgcn_sched_barrier(0);')
-    line(indent + '  asm volatile("s_waitcnt lgkmcnt(0)" : %s :: "memory");' % ', '.join(
-        '"+v"(rr%d)' % r for r in range(R)))
-    for r in range(R):
-      line(indent + '  ' + ' '.join('%s = rr%d[%d];' % (cell(source.ident, s, r, c), r, c)
-                                    for c in range(C)))
-    ring_load(v % ring, 'head + %d' % (v + ring), indent + '  ')
-    line(indent + '}')
-
-  def emit_trip_early(guarded):
-    """One trip in the `early` order: per step the LATE part (edge rows, the rest of
-    every level's expression, publishes, stores), then the EARLY part of the next step,
-    then the barrier."""
-    stages_ = [i for i in insts if i.stage is not None]
-    for u in range(period):
-      line('    {  // unrolled step %d, late part' % u)
-      if source.up or source.down:
-        publish(source, u, slot(source, u, 0))
-      scope = set()
-      lines, keys = edge_read_lines(stages_[0], u, scope)
-      scope |= keys
-      for text in lines:
-        line(text)
-      for k, inst in enumerate(stages_):
-        stamp(k)           # closes the part before this level (k = 0: the barrier's)
-        by_name = {(n, tuple(rel)): src for src, rel, n in inst.reads}
-        if k + 1 < len(stages_):      # the next level's edge rows, ahead of this level
-          lines, keys = edge_read_lines(stages_[k + 1], u, scope)
-          scope |= keys
-          for text in lines:
-            line(text)
-        line('      {')
-        ctype = builtin_type(inst.c_type)
-        if inst.final:
-          line('        %s out_tile[%d][%d];' % (ctype, RP, C))
-        if guarded:
-          if inst.final:
-            for r in range(RP):
-              line('        ' + ' '.join('out_tile[%d][%d] = 0;' % (r, c) for c in range(C)))
-          line('        if (%s) {' % needed(inst, u)[0])
-        order = inst.pre_rows + [r for r in range(R) if r not in inst.pre_rows]
-        for r in order:
-          for c in range(C):
-            def load(tensor, rel, u=u, r=r, c=c, inst=inst, by_name=by_name):
-              return operand(inst, by_name[(tensor, tuple(rel))], tuple(rel), u, r, c)
-            target = ('out_tile[%d][%d]' % (r, c)) if inst.final else \
-                cell(inst.ident, slot(inst, u, 0), r, c)
-            if inst.pre and r in inst.pre_rows:
-              line('        %s = %s;' % (target, specmod.substitute_loads(
-                  inst.rest.replace(kernel_common.PRE_MARK, target), load)))
-            else:
-              cell_assignment(inst.stage, target, load, line, '        ')
-        if inst.up or inst.down:
-          publish(inst, u, slot(inst, u, 0))
-        if guarded:
-          line('        }')
-        if inst.final:
-          line('        const i64 z = head + %d;' % (u - L))
-          line('        const bool z_ok = z >= z0 && z < z1;')
-          line('        const unsigned rows_now = z_ok ? st_rows : 0u;')
-          line('        %s* const out_plane = g_out + (z_ok ? z : z0) * plane;' % T)
-          for r in range(R):
-            line('        { const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_'
-                 'rsrc((void*)out_plane, 0, (rows_now >> %d) & 1u ? (int)plane_bytes : 0, '
-                 '0x27000);' % r)
-            line('          if (!RAGGED) { %s v;%s __builtin_amdgcn_raw_buffer_store_%s('
-                 '__builtin_bit_cast(%s, v), rs, st_voff, (unsigned)(%d * W * %d), %s); }' % (
-                     vec, ''.join(' v[%d] = %s;' % (c, out_cell(r, c))
-                                  for c in range(C)), suffix, buf_type, r, elem, st_aux))
-            line('          else {%s }' % ''.join(
-                ' __builtin_amdgcn_raw_buffer_store_b32(%s_bits(%s), rs, st_voff%d, '
-                '(unsigned)(%d * W * %d), %s);' % (name, out_cell(r, c), c, r, elem, st_aux)
-                for c in range(C)))
-            line('        }')
-        line('      }')
-      stamp(len(stages_))
-      line('    }')
-      emit_early(u + 1, guarded, '    ')
-      if stamps:
-        stamp(0)
-      line('    soda_lds_barrier();')
-      stamp(len(insts))
-
   def emit_trip(guarded):
-    if early:
-      return emit_trip_early(guarded)
     for u in range(period):
       line('    {  // unrolled step %d' % u)
       edges_done = set()
@@ -878,8 +715,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
 
   stages = [i for i in insts if i.stage is not None]
   line('  i64 n = 0;')
-  if early:
-    emit_early(0, lean_fill, '  ')
   if lean_fill:
     firsts = [needed(i, 0)[1] for i in stages]
     lasts = [needed(i, 0)[2] for i in stages]
@@ -917,14 +752,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('  const int wave = __builtin_amdgcn_readfirstlane('
        '__builtin_amdgcn_workitem_id_x() >> 6);')
   # (a 1-D grid: the kernel places its tiles itself, XCD by XCD)
-  if prio:
-    # issue priority by band: the two wavefronts a SIMD holds - bands w and w + G / 2 -
-    # run the same code in the same phase and wait together; a raised priority for one of
-    # them staggers them (1: the first half of the bands, 2: the second half, 3: taking
-    # turns part by part - see stamp())
-    if prio in (1, 2):
-      line('  if (%s) __builtin_amdgcn_s_setprio(3);' % (
-          'wave < %d' % (G // 2) if prio == 1 else 'wave >= %d' % (G // 2)))
   line('  const unsigned L = __builtin_amdgcn_workgroup_id_x();')
   line('  const unsigned SX = (unsigned)a.param[1] & 0xffffu, '
        'SY = (unsigned)a.param[1] >> 16;')
@@ -993,10 +820,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     entry['mask_loads'] = 1
   if lean_fill:
     entry['lean_fill'] = 1
-  if prio:
-    entry['prio'] = int(prio)
-  if early:
-    entry['early'] = 1
   if wide_stores:
     entry['wide_stores'] = int(wide_stores)
   return '\n'.join(o) + '\n', entry
