@@ -421,11 +421,15 @@ def measure(app, dims, iterate, steps, warmup, max_depth=0, split='', no_tune=Fa
   schedule = program.schedule(dims, iterate)
   # the shader clock under this load, measured in-run: a probe wavefront sleeps beside
   # ~30 ms of the same sweeps and counts shader cycles against the constant 100 MHz clock
-  probe_sweeps = max(1, int(0.03 / max(wall / steps, 1e-6)))
-  clock = program.shader_clock_during(
-      lambda: [program.sweep(ip, op, dims, iterate) for _ in range(probe_sweeps)],
-      probe_sweeps * wall / steps)
-  sync()
+  # (not in the profiling passes, which repeat a given split: their kernel counts stay
+  # sweeps x launches per sweep)
+  clock = None
+  if not split:
+    probe_sweeps = max(1, int(0.03 / max(wall / steps, 1e-6)))
+    clock = program.shader_clock_during(
+        lambda: [program.sweep(ip, op, dims, iterate) for _ in range(probe_sweeps)],
+        probe_sweeps * wall / steps)
+    sync()
   valid = specmod.valid_cells(spec, dims, iterate)
   nominal = cells * iterate
   ms_per_step = wall / steps * 1e3

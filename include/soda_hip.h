@@ -171,7 +171,12 @@ typedef struct soda_hip_kernel {
                            (what the kernel's own pipeline costs) */
   int32_t step_ns_one;  /* the same with at most one workgroup per CU */
   int32_t stream_gbps;  /* GB/s of step_bytes the kernel sustains on arrays far larger
-                           than the caches (its HBM-bound rate) */
+                           than the caches.  A PRICE constant, not a physical bandwidth:
+                           the price charges (chunk + fill rows) steps of step_bytes each,
+                           while a short chunk skips the loads past its last row and never
+                           stores during fill, so with a measured stream_chunk the figure
+                           can exceed the 8 TB/s of HBM and is valid at THAT chunk length
+                           only (the launcher uses it there and nowhere else) */
   int32_t xcd_tiles;  /* N > 0: the kernel takes a 1-D grid and places its tiles
                          itself, XCD by XCD (N = most tiles per super-tile; 1 =
                          the plain round-robin deal): the launcher cuts the plane of tiles

@@ -276,6 +276,12 @@ def main():
                         one=[small, one['blocks'], one['steps'], one['us']],
                         stream=[big, stream['blocks'], stream['steps'], stream['us']],
                         between=[between, mid['blocks'], mid['steps'], mid['us']]))
+      if gbps > 8000 and not (chosen or {}).get('stream_chunk'):
+        # only a short measured chunk (loads past its last row skipped, no stores during
+        # fill) may price above the HBM peak: the figure is a price constant valid at that
+        # chunk length (include/soda_hip.h); anything else is a measurement gone wrong
+        print('WARNING: %s: stream_gbps %.0f above the HBM peak without a measured chunk'
+              % (k['name'], gbps), flush=True)
       print('%-28s full %6.0f ns/step (%4d wgs)  one %6.0f ns/step (%4d wgs)  stream %5.0f '
             'GB/s of step_bytes (%4d wgs, %.0f ns/step)  at %d: %.0f ns/step -> fade %d..%d MiB'
             % (k['name'], full['step_ns'], full['blocks'], one['step_ns'], one['blocks'],
