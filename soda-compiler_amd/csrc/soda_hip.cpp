@@ -432,7 +432,7 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
         // fetched (jacobi3d box 504^3: 5 chunks of 104 planes in one round and 11 of
         // 48 in two both walk 112 steps; the long ones read 8 % less).  (Round 3 also
         // measured the chunk by its PRICED time - cfg4 +16 %, cfg2 +7 % - and the shortest
-        // chunk on ties - cfg5 +3 %: DESIGN.md 4.3; both switches are gone.)
+        // chunk on ties - cfg5 +3 %: docs/DESIGN_HISTORY.md 4.3; both switches are gone.)
         if (best_cost < 0 || cost <= best_cost) {
           best_cost = cost;
           best = chunk;

@@ -176,7 +176,7 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   With pairs=1 the lane-crossing operands stay two scalars so that each shift folds
   into a scalar add (kernel_common: pk2_shifted; jacobi2d depth 16: 627 -> 610 us).
 
-  Measured and removed (all bit-exact, none a gain twice): one
+  Measured and removed (docs/DESIGN_HISTORY.md 4.1a, 4.1d; all bit-exact, none a gain twice): one
   barrier per 2 or 3 rows instead of one per row (607 vs 602 us per depth-16 launch),
   wavefront roles rotated per workgroup (549 vs 543), non-temporal ring loads and
   stores of the deep kernels (+-0.4 % of cfg4), the ring read as two ds_read_b128 plus

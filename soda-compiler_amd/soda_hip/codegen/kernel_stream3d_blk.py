@@ -2,7 +2,7 @@
 every wavefront, the plane tile of a workgroup cut into horizontal bands, one per
 wavefront, and only the bands' EDGE ROWS exchanged through LDS.
 
-Why: the wave-pipelined form (kernel_stream3d_wp: one level per
+Why (docs/DESIGN_HISTORY.md 4.1b): the wave-pipelined form (kernel_stream3d_wp: one level per
 wavefront, whole plane tiles handed from wavefront to wavefront) is latency-bound -
 its wavefronts wait for each other at the per-plane barrier 59 % of the time, a
 level's whole tile makes an LDS round trip per plane, and 48 KiB + 168 VGPRs per
@@ -117,7 +117,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   the DPP shift folded into a v_add_f32_dpp).  Same IEEE operations in the same
   order as the scalar form.
   Fixed parts of the design (they were options while they were being measured; the A/B
-  figures are in DESIGN.md 4.1d and profiles/r03_blk_variants.txt, r03_blk_stamps.txt):
+  figures are in docs/DESIGN_HISTORY.md 4.1d and profiles/r03_blk_variants.txt, r03_blk_stamps.txt):
   * the tiles' output columns start on multiples of ALIGN_OUT = 16 cells and are a
     multiple of 16 wide, so that the row segments of neighbouring workgroups meet on
     64-byte boundaries (tools/tile3dbench.hip, this kernel's access pattern without the

@@ -439,7 +439,7 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
         bool(getattr(args, 'no_exchange_tune', False)) or world == 1
     # Which (exchange period, order) pairs to time: unless given on the command line,
     # E = 1, 2, 4, 8 x the deepest fused kernel, each serial and overlapped - the two
-    # knobs that decide an N > 1 run and that one GPU cannot measure (DESIGN.md 6)
+    # knobs that decide an N > 1 run and that one GPU cannot measure (DESIGN.md 7)
     if given:
       pairs = [(args.exchange or auto_exchange(dims[-1] // world, reach, deepest,
                                                args.iterate),

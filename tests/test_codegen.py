@@ -269,7 +269,7 @@ def test_3d_wave_pipelined_kernel_and_its_constraints(tmp_path):
 
 
 def test_3d_block_form_options_pairs_and_ring(tmp_path):
-  """Experimental options of the block form: packed pair-rows and
+  """Experimental options of the block form (docs/DESIGN_HISTORY.md 4.1b): packed pair-rows and
   the per-wavefront LDS ring fed by LDS-direct loads.  A ring kernel waits with a
   COUNTED vmcnt, so it must issue the same number of stores every step and must
   not contain a release fence at its barrier."""

@@ -82,7 +82,7 @@ def test_analysis_matches_reference(key):
   assert len(ours) == len(ref['stages'])
   # A window that excludes the store point makes the reference print a negative
   # margin (`p<dims[0]--1`, which no compiler accepts); here every box contains the
-  # cell itself (DESIGN.md 7, deliberate deviation), which also moves the boxes
+  # cell itself (DESIGN.md 2, deliberate deviation), which also moves the boxes
   # of the stages downstream: loop bounds are compared for the other programs.
   one_sided = any(min(t['loop_lo'] + t['loop_hi_margin']) < 0 for t in ref['stages'])
   for mine, theirs in zip(ours, ref['stages']):

@@ -131,7 +131,7 @@ SHIPPED_FORMS = [
     ('seidel2d', dict(wave_groups=4, pairs=2, vgpr_budget=250, ring=6)),
     ('blur', dict(wave_groups=4, vgpr_budget=200, ring=6)),
 ]
-# ... and the forms that were measured and not shipped.  They
+# ... and the forms that were measured and not shipped (docs/DESIGN_HISTORY.md 4.1a).  They
 # stay correct: ALWAYS_TESTED_EXPERIMENTAL of them run in every test session (the
 # same ones on any day: fixed test ids), all of them with SODA_TEST_ALL_FORMS=1.
 EXPERIMENTAL_FORMS = [

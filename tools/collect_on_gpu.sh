@@ -63,3 +63,6 @@ while IFS='|' read -r name wargs; do
   bash tools/sq_counters.sh ${tag}_${name} $wargs ${sp:+--split $sp} > /dev/null 2>&1 || echo "sq $name FAILED"
   echo "sq $name done"
 done < $out/pmc_${tag}_workloads.txt
+
+# what soda_hip_plan_tune's streaming step finds on this box (profiles/rNN_stream_chunk.txt)
+bash tools/stream_tune_probe.sh $out/${tag}_stream_tune_collect.log || true

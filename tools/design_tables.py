@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Prints the two markdown tables of DESIGN.md section 5 from the committed
+"""Prints the two markdown tables of DESIGN.md section 6 from the committed
 profiles (profiles/<tag>_all_samples.json, <tag>_traffic.json + kernel times)."""
 import json
 import os

@@ -4,7 +4,7 @@
       --size ... --iterate N --steps 1 --warmup 0 --cpu-seconds 0
   python3 tools/launch_trace.py DIR A
 prints the launches of the LAST sweep in order (kernel, µs, workgroups).  This is
-how the 2x anomalies of the XCD super-tile padding were found."""
+how the 2x anomalies of the XCD super-tile padding were found (docs/DESIGN_HISTORY.md 4.1b)."""
 import csv
 import glob
 import os

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What one rank's super-step costs at the slab sizes of 1/2/4/8 ranks, on ONE
 GPU: own rows + 2 E ghost rows, E iterations, for several exchange periods E and
-caps on the fused depth.  Feeds runtime/dist.py: auto_exchange and DESIGN.md 6.
+caps on the fused depth.  Feeds runtime/dist.py: auto_exchange and DESIGN.md 7.
 With `split` the super-step is cut as the overlapping schedule cuts it (two
 boundary bands first, then the interior: dist.band_plan), which prices what
 hiding the exchange costs in compute.
