@@ -1332,6 +1332,12 @@ def build_rccl_standin(tmp_path):
 def test_run_slab_with_two_and_three_ranks_over_the_rccl_standin(tmp_path, app, dims,
                                                                  world, iterate, exchange,
                                                                  order):
+  run_slab_over_the_standin(tmp_path, build_rccl_standin(tmp_path), app, dims, world,
+                            iterate, exchange, order)
+
+
+def run_slab_over_the_standin(tmp_path, standin, app, dims, world, iterate, exchange,
+                              order):
   """soda_hip_run_slab - the C slab driver: ncclSend / ncclRecv inside one group per
   super-step on the caller's stream, then the sweep - with world > 1.  RCCL refuses two
   ranks on one GPU and this box has one, so the ranks are host threads over a
@@ -1342,7 +1348,6 @@ def test_run_slab_with_two_and_three_ranks_over_the_rccl_standin(tmp_path, app, 
   import sys
   from conftest import ROOT
   from soda_hip.codegen import spec as specmod
-  standin = build_rccl_standin(tmp_path)
   r = subprocess.run(
       [sys.executable, os.path.join(ROOT, 'tests', 'rccl_standin_worker.py'), standin,
        app, 'x'.join(map(str, dims)), str(world), str(iterate), str(exchange),
