@@ -671,13 +671,14 @@ def test_generated_cpp_host_multi_gpu_entry_with_several_ranks(tmp_path, app, di
                          '-DSODA_HIP_MAIN', '-DSODA_HIP_MULTI_GPU',
                          '-D__HIP_PLATFORM_AMD__', '-I', '/opt/rocm/include',
                          '-I', os.path.join(ROOT, 'include'), str(src), '-L', csrc,
-                         '-lsoda_hip', '-L', str(tmp_path), '-lrccl', '-lpthread',
-                         '-Wl,-rpath,' + csrc, '-Wl,-rpath,' + str(tmp_path),
+                         '-lsoda_hip', '-L', os.path.dirname(standin), '-lrccl', '-lpthread',
+                         '-Wl,-rpath,' + csrc, '-Wl,-rpath,' + os.path.dirname(standin),
                          '-Wl,-rpath,/opt/rocm/lib', '-o', str(exe)])
   blob = os.path.join(gpu_util.BLOBS, app + '.hsaco')
   env = dict(os.environ, SODA_ITERATE=iterate, SODA_GPUS=ranks,
              SODA_HIP_REHEARSE_RANKS_ON_ONE_GPU='1',
-             LD_LIBRARY_PATH=str(tmp_path) + ':' + os.environ.get('LD_LIBRARY_PATH', ''))
+             LD_LIBRARY_PATH=os.path.dirname(standin) + ':' +
+             os.environ.get('LD_LIBRARY_PATH', ''))
   r = subprocess.run([str(exe), blob] + [str(d) for d in dims], capture_output=True,
                      text=True, env=env, timeout=600)
   assert r.returncode == 0, r.stderr[-2000:]
@@ -1299,13 +1300,20 @@ def test_tuned_split_changes_speed_only(app, shape, iterate):
     prog.close()
 
 
+_STANDIN = {}
+
+
 def build_rccl_standin(tmp_path):
   """tests/rccl_standin: ncclSend / ncclRecv / groups for ranks that are threads of
   one process on one GPU (a TEST library; soname librccl.so so that libsoda_hip's
-  dlopen resolves to it inside the worker process only)."""
+  dlopen resolves to it inside the worker process only).  Built once per test session."""
   import subprocess
+  import tempfile
   from conftest import ROOT
-  out = os.path.join(str(tmp_path), 'librccl.so')
+  if _STANDIN.get('path') and os.path.exists(_STANDIN['path']):
+    return _STANDIN['path']
+  _STANDIN['dir'] = tempfile.TemporaryDirectory(prefix='rccl_standin_')
+  out = _STANDIN['path'] = os.path.join(_STANDIN['dir'].name, 'librccl.so')
   subprocess.check_call([
       'g++', '-O1', '-fPIC', '-shared', '-std=c++17', '-Wl,-soname,librccl.so',
       '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include',
