@@ -492,8 +492,11 @@ def run_single(args):
   if is_headline(args) and not args.no_other_configs and not args.split:
     others = []
     for tag, app, dims, iterate in OTHER_CONFIGS:
-      line, _ = measure(app, dims, iterate, OTHER_STEPS, OTHER_WARMUP, jit=args.jit)
-      others.append(other_config_entry(tag, line))
+      try:
+        line, _ = measure(app, dims, iterate, OTHER_STEPS, OTHER_WARMUP, jit=args.jit)
+        others.append(other_config_entry(tag, line))
+      except Exception as e:   # noqa: BLE001 - a secondary config must not cost the headline
+        others.append(dict(config=tag, error='%s: %s' % (type(e).__name__, str(e)[:300])))
     result['config']['other_configs'] = others
   if args.cpu_seconds > 0:
     result['cpu_baseline'] = cpu_baseline(spec, list(args.size), args.cpu_seconds)
