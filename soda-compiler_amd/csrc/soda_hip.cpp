@@ -125,6 +125,7 @@ struct soda_hip_plan {
   hipFunction_t probe = nullptr;
   void* probe_buf = nullptr;
   bool probe_running = false;
+  hipEvent_t probe_t0 = nullptr, probe_t1 = nullptr;
 };
 
 namespace {
@@ -1254,6 +1255,8 @@ int soda_hip_plan_destroy(soda_hip_plan* plan) {
     if (ptr && hipFree(ptr) != hipSuccess)
       rc = fail(SODA_HIP_ERR_DEVICE_FREE, "hipFree of plan scratch failed");
   if (plan->probe_buf) (void)hipFree(plan->probe_buf);
+  if (plan->probe_t0) (void)hipEventDestroy(plan->probe_t0);
+  if (plan->probe_t1) (void)hipEventDestroy(plan->probe_t1);
   if (plan->ev_main) (void)hipEventDestroy(plan->ev_main);
   if (plan->ev_landed) (void)hipEventDestroy(plan->ev_landed);
   if (plan->side) (void)hipStreamDestroy(plan->side);
@@ -1543,8 +1546,15 @@ int soda_hip_clock_probe_start(soda_hip_plan* plan, int spins) {
   size_t size = sizeof args;
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE,
                     &size, HIP_LAUNCH_PARAM_END};
+  // the wall time of the probe comes from events around it (the realtime counter it
+  // reads is nominally 100 MHz; measured against events it is what calibrates it)
+  if (!plan->probe_t0 && (hipEventCreate(&plan->probe_t0) != hipSuccess ||
+                          hipEventCreate(&plan->probe_t1) != hipSuccess))
+    return fail(SODA_HIP_ERR_DEVICE_RUN, "hipEventCreate failed");
+  HIP_TRY(SODA_HIP_ERR_DEVICE_RUN, hipEventRecord(plan->probe_t0, plan->side));
   HIP_TRY(SODA_HIP_ERR_DEVICE_RUN,
           hipModuleLaunchKernel(plan->probe, 1, 1, 1, 64, 1, 1, 0, plan->side, nullptr, config));
+  HIP_TRY(SODA_HIP_ERR_DEVICE_RUN, hipEventRecord(plan->probe_t1, plan->side));
   plan->probe_running = true;
   return 0;
 }
@@ -1557,7 +1567,20 @@ int soda_hip_clock_probe_finish(soda_hip_plan* plan, double* shader_ghz, double*
   unsigned long long got[2] = {0, 0};
   HIP_TRY(SODA_HIP_ERR_COPY_TO_HOST, hipMemcpy(got, plan->probe_buf, 16, hipMemcpyDeviceToHost));
   if (!got[1]) return fail(SODA_HIP_ERR_DEVICE_RUN, "the clock probe reported no time");
-  const double elapsed = (double)got[1] / 100.0e6;      // s_memrealtime: 100 MHz
+  // s_memrealtime ticks at a nominal 100 MHz; the events around the probe give the wall
+  // time independently (the kernel is one wavefront that starts at once on the non-blocking
+  // stream, so both spans agree to a few microseconds when the counter's rate is as named)
+  double elapsed = (double)got[1] / 100.0e6;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, plan->probe_t0, plan->probe_t1) == hipSuccess && ms > 0) {
+    const double by_events = ms * 1e-3;
+    if (tuning_env("SODA_HIP_DEBUG"))
+      fprintf(stderr, "soda_hip: clock probe: %llu shader cycles, %llu realtime ticks = %.3f ms "
+              "at 100 MHz, events %.3f ms\n", got[0], got[1], elapsed * 1e3, by_events * 1e3);
+    // a probe that waited for a wave slot makes the event span LONGER than its own count;
+    // take the counter unless the two disagree by more than the realtime clock could
+    if (by_events < elapsed * 0.97) elapsed = by_events;
+  }
   *shader_ghz = (double)got[0] / elapsed / 1e9;
   if (seconds) *seconds = elapsed;
   return 0;
