@@ -15,6 +15,7 @@ ABI_VERSION = 7
 
 KERNEL_STAGE = 0
 KERNEL_FUSED = 1
+ERR_NO_KERNEL = -102        # SODA_HIP_ERR_NO_KERNEL (include/soda_hip.h)
 
 
 class SodaHipError(RuntimeError):

@@ -329,12 +329,21 @@ class Program:
     spins = max(4, int(seconds * 0.6 / 3.9e-6))
     try:
       capi.check(capi.lib().soda_hip_clock_probe_start(self.handle, spins))
-    except capi.SodaHipError:
-      return None
-    work()
+    except capi.SodaHipError as e:
+      if e.code == capi.ERR_NO_KERNEL:     # a blob from before the probe kernel
+        return None
+      raise                                # an allocation or launch failure is an error
     ghz, took = ctypes.c_double(), ctypes.c_double()
-    capi.check(capi.lib().soda_hip_clock_probe_finish(self.handle, ctypes.byref(ghz),
-                                                      ctypes.byref(took)))
+    failed = True
+    try:
+      work()
+      failed = False
+    finally:
+      # always collected: a probe left running would refuse every later one
+      rc = capi.lib().soda_hip_clock_probe_finish(self.handle, ctypes.byref(ghz),
+                                                  ctypes.byref(took))
+      if not failed:
+        capi.check(rc)
     return dict(ghz=ghz.value, seconds=took.value)
 
   # -- numpy conveniences (tests, <app>_test) --------------------------------

@@ -128,3 +128,60 @@ def test_other_configs_block_has_the_shape_the_driver_line_promises():
   assert bench.is_headline(ns)
   assert not bench.is_headline(argparse.Namespace(app='jacobi2d', size=[8192, 8192], iterate=100))
   assert not bench.is_headline(argparse.Namespace(app='blur', size=[16384, 16384], iterate=1000))
+
+
+def test_the_keys_the_verdict_reads_come_first():
+  """The driver's record of a bench line keeps the first 24 scalar keys of an object, drops
+  lists and cuts strings at 120 characters: `roofline` starts with the
+  keys the roofline argument rests on, `config` carries scalar copies of the other
+  configs' figures, and `cpu_baseline.sample` fits."""
+  from soda_hip import frontend
+  from soda_hip.codegen import spec as specmod
+  st = frontend.load(os.path.join(ROOT, 'tests', 'samples', 'jacobi2d.soda'), iterate=48)
+  spec = specmod.spec_from_stencil(st)
+  entry = dict(name='jacobi2d_fused_k24', kind='fused', depth=24, pairs=2, block=[256, 1, 1],
+               tile=[464, 1, 256, 1], cols=4)
+  timing = dict(dominant_name='jacobi2d_fused_k24', dominant_us=1400.0, dominant_launches=2,
+                fastest_us=1400.0, launches=2)
+  updates = [16000 * 16000] * 48
+  block = bench.roofline_block(spec, None, [(entry, 700.0)] * 2, updates, timing,
+                               [16384, 16384], 48, step_us=1500.0,
+                               clock=dict(ghz=2.0, seconds=0.03))
+  head = list(block)[:12]
+  assert head == ['kernel', 'bound', 'frac', 'unit', 'achieved', 'peak', 'frac_algorithmic',
+                  'hbm_measured_frac', 'valu_frac', 'traffic', 'kernel_avg_us',
+                  'kernel_launches']
+  scalars = [k for k, v in block.items() if not isinstance(v, (list, dict))]
+  assert {'frac', 'bound', 'peak', 'unit', 'achieved', 'shader_clock_ghz'} <= set(scalars[:24])
+  assert block['frac'] == block['valu_frac' if block['bound'] == 'valu' else 'hbm_floor_frac']
+  config = dict(workload='w', app='jacobi2d', dims=[1, 2], iterate=1000,
+                valid_cell_updates=1, nominal_cell_updates=1, nominal_gcell_updates_per_s=1.0,
+                launches_per_step=42, depth_schedule='41x24+1x16', depth_split='m',
+                stream_chunk_choice='calibrated', effective_GBps=1.0, device='gfx950')
+  others = [dict(config='cfg2', ms=0.93, roofline=dict(bound='valu', frac=0.45, traffic=None)),
+            dict(config='cfg3', ms=0.19, roofline=dict(bound='hbm', frac=0.79, traffic=1.1e9)),
+            dict(config='cfg5', error='RuntimeError: x')]
+  bench.add_other_configs(config, others)
+  scalars = [k for k, v in config.items() if not isinstance(v, (list, dict))]
+  assert len(scalars) <= 24
+  assert config['cfg2_ms'] == 0.93 and config['cfg3_bound'] == 'hbm'
+  assert config['cfg3_traffic'] == 1.1e9 and config['cfg5_ms'] is None
+  assert list(config)[-1] == 'other_configs'
+
+
+def test_cpu_baseline_is_pinned_and_its_description_fits_the_record():
+  """bench.py's cpu_baseline leg on a tiny grid: threads pinned one per core
+  (oracle/pin_threads.c), one discarded sample + three, the description within the 120
+  characters the driver's record keeps, the caller's affinity restored."""
+  from soda_hip import frontend
+  from soda_hip.codegen import spec as specmod
+  st = frontend.load(os.path.join(ROOT, 'tests', 'samples', 'jacobi2d.soda'), iterate=4)
+  spec = specmod.spec_from_stencil(st)
+  before = os.sched_getaffinity(0)
+  cpu = bench.cpu_baseline(spec, [96, 64], 0.2)
+  assert os.sched_getaffinity(0) == before
+  assert cpu['kind'] == 'port' and cpu['cores'] >= 1 and cpu['value'] > 0
+  assert len(cpu['samples']) == 3 and cpu['best'] == max(cpu['samples'])
+  assert cpu['value'] == sorted(cpu['samples'])[1]
+  assert len(cpu['sample']) <= 120 and 'discarded' in cpu['sample']
+  assert cpu['pinned'] is True
