@@ -221,6 +221,209 @@ def run_slab(engine, plan, arrays, iterate, margins_of, dist, ghosts_ready=False
   return src, exchanges
 
 
+# ---------------------------------------------------------------------------
+# slabs re-cut to the shrinking valid box
+# ---------------------------------------------------------------------------
+# The static cut above gives every rank the same rows for the whole run.  Under the
+# reference's semantics the valid box shrinks by the window every iteration
+# (core.py:794-835, host.py:1082-1091): the first and last ranks lose r rows per
+# iteration, the ranks in the middle none, and a step costs what the slowest rank costs -
+# jacobi2d 16384^2 x1000 on 4 or 8 ranks is capped at 93.9 % by that alone, jacobi3d
+# 512^3 x200 on 8 ranks at 61 % (ranks 0 and 7 own planes 0-63 and 448-511 and have
+# nothing left to do after iteration 64).  Here every super-step cuts the rows its
+# OUTPUT level defines evenly again; rows that change owner travel in the same grouped
+# send / recv as the ghost rows.
+def _even_cut(lo, hi, world):
+  """world + 1 cut points of [lo, hi) (an empty range: all equal to lo)."""
+  pts, at = [lo], lo
+  for a, b in slab_bounds(max(0, hi - lo), world):
+    at += b - a
+    pts.append(at)
+  return pts
+
+
+def _intersect(a, b):
+  lo, hi = max(a[0], b[0]), min(a[1], b[1])
+  return (lo, hi) if hi > lo else None
+
+
+class RecutPlan:
+  """Geometry of a run whose slabs are cut afresh every super-step.
+
+  Global rows of the outermost dimension throughout.  Super-step s starts after
+  `done` iterations and advances `step` = min(exchange, iterate - done) more:
+    owned[s][r] = rows of its INPUT level rank r holds (it produced them; s = 0: the even
+                  cut of the whole grid, how the input arrives),
+    cuts[s]     = world + 1 cut points of the rows its OUTPUT level defines,
+                  [(done + step) r_lo, rows - (done + step) r_hi), cut evenly,
+    need[s][r]  = rows of the input level rank r reads: its output rows widened by the
+                  reach of `step` iterations (None: the rank has no output rows).
+  Before super-step s rank r sends need[s][q] & owned[s][r] to every other rank q and
+  receives need[s][r] & owned[s][q] - ghost rows and rows changing owner alike; with
+  thin slabs (cfg5 on 8 ranks: 14 planes each at the end, 16 or 32 of reach) the
+  partner is not always the immediate neighbour.  A rank's arrays span the hull of
+  everything it ever holds, [base, base + local_extent), at a fixed offset."""
+
+  def __init__(self, dims, rank, world, r_lo, r_hi, exchange, iterate):
+    self.dims = list(dims)
+    self.rank, self.world = rank, world
+    self.r_lo, self.r_hi = r_lo, r_hi
+    self.exchange = max(1, min(exchange, iterate))
+    self.iterate = iterate
+    rows = dims[-1]
+    self.steps = []                 # (done, step) per super-step
+    self.owned, self.cuts, self.need = [], [], []
+    level = [(a, b) for a, b in slab_bounds(rows, world)]
+    done = 0
+    while done < iterate:
+      step = min(self.exchange, iterate - done)
+      lo, hi = (done + step) * r_lo, rows - (done + step) * r_hi
+      cut = _even_cut(lo, max(lo, hi), world)
+      need = [(cut[r] - step * r_lo, cut[r + 1] + step * r_hi)
+              if cut[r + 1] > cut[r] else None for r in range(world)]
+      self.steps.append((done, step))
+      self.owned.append(level)
+      self.cuts.append(cut)
+      self.need.append(need)
+      level = [(cut[r], cut[r + 1]) for r in range(world)]
+      done += step
+    self.final = level              # rows of the result every rank ends up with
+    self.start, self.stop = self.owned[0][rank]          # level-0 rows (the input)
+    self.own = self.stop - self.start
+    held = [self.owned[0][rank]] + [n[rank] for n in self.need if n[rank]]
+    self.base = min(a for a, _ in held)
+    self.local_extent = max(b for _, b in held) - self.base
+    self.local_dims = self.dims[:-1] + [self.local_extent]
+    self.ghost_lo = self.start - self.base       # where the level-0 rows go
+    self.final_rows = self.final[rank]           # global; local = minus base
+
+  def local(self, rows):
+    return rows[0] - self.base, rows[1] - self.base
+
+  def messages(self, s):
+    """(sends, recvs) of this rank before super-step s: [(peer, (lo, hi) global rows)],
+    ascending peers - both sides enumerate a pair's rows from the same tables."""
+    sends, recvs = [], []
+    mine = self.owned[s][self.rank]
+    for q in range(self.world):
+      if q == self.rank:
+        continue
+      if self.need[s][q] and mine[1] > mine[0]:
+        rows = _intersect(self.need[s][q], mine)
+        if rows:
+          sends.append((q, rows))
+      theirs = self.owned[s][q]
+      if self.need[s][self.rank] and theirs[1] > theirs[0]:
+        rows = _intersect(self.need[s][self.rank], theirs)
+        if rows:
+          recvs.append((q, rows))
+    return sends, recvs
+
+  def pieces(self, s):
+    """Super-step s, bands first: ([band, ...], interior), each (out_lo, out_hi) global
+    output rows - the bands are the rows other ranks need for super-step s + 1, the
+    interior the rest of this rank's output.  None when there is nothing to gain: the last
+    super-step, no output rows, nobody waiting, or bands that meet (a thin slab)."""
+    if s + 1 >= len(self.steps):
+      return None
+    lo, hi = self.cuts[s][self.rank], self.cuts[s][self.rank + 1]
+    if hi <= lo:
+      return None
+    below = [n[1] for n in self.need[s + 1][:self.rank] if n and n[1] > lo]
+    above = [n[0] for n in self.need[s + 1][self.rank + 1:] if n and n[0] < hi]
+    b_lo = min(hi, max(below)) if below else lo
+    b_hi = max(lo, min(above)) if above else hi
+    if (b_lo == lo and b_hi == hi) or b_lo >= b_hi:
+      return None
+    bands = ([(lo, b_lo)] if b_lo > lo else []) + ([(b_hi, hi)] if b_hi < hi else [])
+    return bands, (b_lo, b_hi)
+
+  def max_rows_per_iteration(self):
+    """Sum over the super-steps of the rows the BUSIEST rank sweeps per iteration (its
+    output rows plus the reach it recomputes, averaged over the step's iterations) - what
+    a step costs when a row costs the same everywhere; for DESIGN.md's before / after
+    table."""
+    total = 0
+    for (done, step), need in zip(self.steps, self.need):
+      widest = max([b - a for n in need if n for a, b in [n]] or [0])
+      # iteration i of the step sweeps the input rows minus i reaches
+      total += sum(max(0, widest - i * (self.r_lo + self.r_hi)) for i in range(1, step + 1))
+    return total
+
+
+def exchange_rows(array, plan, s, dist):
+  """array: torch tensor of shape reversed(plan.local_dims).  The grouped send / recv
+  of RecutPlan.messages(s)."""
+  if plan.world == 1:
+    return
+  signed = {'torch.uint16': 'int16', 'torch.uint32': 'int32', 'torch.uint64': 'int64'}
+  if str(array.dtype) in signed:
+    import torch
+    array = array.view(getattr(torch, signed[str(array.dtype)]))
+  sends, recvs = plan.messages(s)
+  ops = []
+  for peer, rows in sends:
+    a, b = plan.local(rows)
+    ops.append(dist.P2POp(dist.isend, array[a:b], peer))
+  for peer, rows in recvs:
+    a, b = plan.local(rows)
+    ops.append(dist.P2POp(dist.irecv, array[a:b], peer))
+  if ops:
+    for req in dist.batch_isend_irecv(ops):
+      req.wait()
+
+
+def run_recut(engine, plan, arrays, margins_of, dist, ghosts_ready=False, schedule=None):
+  """run_slab for a RecutPlan: advances the rank's rows plan.iterate iterations;
+  arrays = [A, B, C] of shape reversed(plan.local_dims), A holding the level-0 rows at
+  [plan.ghost_lo, plan.ghost_lo + plan.own) and never written by a sweep.  Returns (array,
+  exchanges): the rank's rows of the result, plan.final_rows, are at plan.local(...) of
+  the returned array.
+
+  Every sweep is a sweep of the SUB-ARRAY of the rows it reads with the outer sides
+  declared valid (the rows there were produced or received): its output box is exactly
+  the rank's rows of the output level, on every rank alike - the first and last rank read
+  from the edge of the valid rows, which is where their sub-arrays start."""
+  a, b, c = arrays
+  schedule = schedule or SerialSchedule()
+  src, exchanges = a, 0
+  dst_cycle = [b, c]
+  pending = ghosts_ready
+  last = len(plan.dims) - 1
+  for s, (done, step) in enumerate(plan.steps):
+    if not pending:
+      schedule.exchange(lambda src=src, s=s: exchange_rows(src, plan, s, dist))
+      exchanges += 1
+    schedule.before_super_step()
+    pending = False
+    lo, hi = margins_of(done)
+    lo, hi = list(lo), list(hi)
+    lo[last] = hi[last] = 0
+    dst = dst_cycle[s % 2]
+
+    def piece(out_rows, final_only):
+      r0 = out_rows[0] - step * plan.r_lo - plan.base
+      r1 = out_rows[1] + step * plan.r_hi - plan.base
+      engine.sweep(src, dst, plan.local_dims, step, lo, hi, rows=(r0, r1),
+                   final_only=final_only)
+    out = (plan.cuts[s][plan.rank], plan.cuts[s][plan.rank + 1])
+    pieces = plan.pieces(s) if schedule.overlapped and plan.world > 1 else None
+    if pieces:
+      bands, interior = pieces
+      for band in bands:
+        piece(band, True)
+      schedule.after_bands()
+      schedule.exchange(lambda dst=dst, s=s: exchange_rows(dst, plan, s + 1, dist))
+      exchanges += 1
+      pending = True
+      piece(interior, True)
+    elif out[1] > out[0]:
+      piece(out, False)
+    src = dst
+  schedule.before_super_step()
+  return src, exchanges
+
+
 def auto_exchange(own_rows, reach, deepest, iterate):
   """Iterations between exchanges: a multiple of the deepest fused kernel, up to
   eight of them, but never more ghost rows than ~15 % of the slab.

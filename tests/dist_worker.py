@@ -77,9 +77,14 @@ class BandsFirst(sdist.SerialSchedule):
 
 def main():
   app, size, iterate, exchange, out_dir = sys.argv[1:6]
-  overlapped = len(sys.argv) > 6 and sys.argv[6].startswith('overlap')
+  mode = sys.argv[6] if len(sys.argv) > 6 else ''
+  # 'recut' / 'recut+overlap[:D]': slabs cut afresh every super-step (RecutPlan)
+  recut = mode.startswith('recut')
+  if recut:
+    mode = mode[len('recut'):].lstrip('+')
+  overlapped = mode.startswith('overlap')
   # 'overlap:D': the CPU engine emulates launches of D iterations
-  launch_depth = int(sys.argv[6].split(':')[1]) if overlapped and ':' in sys.argv[6] else 0
+  launch_depth = int(mode.split(':')[1]) if overlapped and ':' in mode else 0
   dims = [int(v) for v in size.split('x')]
   iterate, exchange = int(iterate), int(exchange)
   rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
@@ -88,7 +93,10 @@ def main():
                      iterate=iterate)
   spec = specmod.spec_from_stencil(st)
   r_lo, r_hi = spec['radius']['lo'][-1], spec['radius']['hi'][-1]
-  plan = sdist.SlabPlan(dims, rank, world, r_lo, r_hi, exchange)
+  if recut:
+    plan = sdist.RecutPlan(dims, rank, world, r_lo, r_hi, exchange, iterate)
+  else:
+    plan = sdist.SlabPlan(dims, rank, world, r_lo, r_hi, exchange)
   dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
   rng = np.random.default_rng(99)
   if dt.kind == 'f':
@@ -96,28 +104,41 @@ def main():
   else:
     full = rng.integers(0, 65536, size=tuple(reversed(dims))).astype(dt)
   shape = tuple(reversed(plan.local_dims))
-  a = torch.zeros(shape, dtype=torch.from_numpy(full[:1]).dtype)
+  # rows nobody filled are NaN / all-ones: a sweep that read one would show
+  poison = np.nan if dt.kind == 'f' else np.iinfo(dt).max
+  a = torch.full(shape, poison, dtype=torch.from_numpy(full[:1]).dtype)
   a[plan.ghost_lo:plan.ghost_lo + plan.own] = torch.from_numpy(
       full[plan.start:plan.stop])
-  b, c = torch.zeros_like(a), torch.zeros_like(a)
+  b, c = torch.full_like(a, poison), torch.full_like(a, poison)
   table = specmod.iteration_margins(spec, iterate)
 
   def margins_of(k):
     return ((0,) * len(dims), (0,) * len(dims)) if k == 0 else table[k - 1]
 
   order = BandsFirst() if overlapped else None
-  result, exchanges = sdist.run_slab(OracleEngine(spec, launch_depth), plan, [a, b, c],
-                                     iterate, margins_of, dist, schedule=order)
-  own = result[plan.ghost_lo:plan.ghost_lo + plan.own].numpy().copy()
+  engine = OracleEngine(spec, launch_depth)
+  if recut:
+    def run(ready):
+      return sdist.run_recut(engine, plan, [a, b, c], margins_of, dist,
+                             ghosts_ready=ready, schedule=order)
+    first, last = plan.local(plan.final_rows)
+    start, stop = plan.final_rows
+  else:
+    def run(ready):
+      return sdist.run_slab(engine, plan, [a, b, c], iterate, margins_of, dist,
+                            ghosts_ready=ready, schedule=order)
+    first, last = plan.ghost_lo, plan.ghost_lo + plan.own
+    start, stop = plan.start, plan.stop
+  result, exchanges = run(False)
+  own = result[first:last].numpy().copy()
   # A was not written and now carries the neighbours' level-0 rows: a second
   # sweep may skip its first exchange and must give the same rows
-  again, fewer = sdist.run_slab(OracleEngine(spec, launch_depth), plan, [a, b, c], iterate,
-                                margins_of, dist, ghosts_ready=True, schedule=order)
+  again, fewer = run(True)
   assert fewer == exchanges - 1, (fewer, exchanges)
-  assert np.array_equal(again[plan.ghost_lo:plan.ghost_lo + plan.own].numpy(), own)
+  assert np.array_equal(again[first:last].numpy(), own, equal_nan=dt.kind == 'f')
   np.save(os.path.join(out_dir, 'rank%d.npy' % rank), own)
   with open(os.path.join(out_dir, 'rank%d.txt' % rank), 'w') as f:
-    f.write('%d %d %d %d\n' % (plan.start, plan.stop, plan.exchange, exchanges))
+    f.write('%d %d %d %d\n' % (start, stop, plan.exchange, exchanges))
   dist.barrier()
   dist.destroy_process_group()
 

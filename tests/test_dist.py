@@ -25,7 +25,7 @@ def free_port():
   return port
 
 
-def run_world(tmp_path, world, app, dims, iterate, exchange, overlap=False):
+def run_world(tmp_path, world, app, dims, iterate, exchange, overlap=False, recut=False):
   env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()),
              WORLD_SIZE=str(world), OMP_NUM_THREADS='2')
   procs = []
@@ -33,7 +33,8 @@ def run_world(tmp_path, world, app, dims, iterate, exchange, overlap=False):
     procs.append(subprocess.Popen(
         [sys.executable, os.path.join(ROOT, 'tests', 'dist_worker.py'), app,
          'x'.join(map(str, dims)), str(iterate), str(exchange), str(tmp_path)] +
-        (['overlap' if overlap is True else 'overlap:%d' % overlap] if overlap else []),
+        [('recut' if recut else '') + ('+' if recut and overlap else '') +
+         ('' if not overlap else 'overlap' if overlap is True else 'overlap:%d' % overlap)],
         env=dict(env, RANK=str(rank), LOCAL_RANK=str(rank))))
   for p in procs:
     assert p.wait(timeout=300) == 0
@@ -97,6 +98,96 @@ def test_slabs_match_single_process(tmp_path, world, app, dims, iterate, exchang
   assert meta[0][0] == 0 and meta[-1][1] == h
   for (a0, a1, _, _), (b0, b1, _, _) in zip(meta, meta[1:]):
     assert a1 == b0
+
+
+@pytest.mark.parametrize('world,app,dims,iterate,exchange,overlap', [
+    (2, 'jacobi2d', (64, 50), 7, 3, False),
+    (3, 'jacobi2d', (48, 47), 5, 2, False),
+    (2, 'blur', (70, 44), 3, 1, False),          # one-sided window: the cuts move one way
+    (3, 'blur', (70, 75), 6, 2, True),
+    (3, 'heat3d', (16, 14, 40), 4, 3, False),
+    (4, 'jacobi2d', (40, 96), 12, 4, False),
+    (4, 'jacobi2d', (40, 96), 12, 4, True),
+    (4, 'jacobi2d', (40, 120), 13, 6, 2),        # pieces of several launches
+    # cfg5's shape in small: the valid range ends far thinner than a level-0 slab, rows
+    # change owner every super-step and partners are not always the nearest rank
+    (4, 'jacobi3d', (20, 18, 24), 8, 2, False),
+    (4, 'jacobi3d', (26, 24, 32), 10, 4, True),
+    (8, 'jacobi3d', (52, 50, 64), 24, 4, False),
+    (8, 'jacobi3d', (52, 50, 64), 24, 4, True),
+    (8, 'jacobi2d', (72, 128), 30, 8, False),
+    (8, 'jacobi2d', (72, 128), 30, 8, True),
+    # more ranks than rows at the end (8 valid rows on 8 ranks, then fewer than ranks)
+    (8, 'jacobi2d', (40, 40), 17, 3, False),
+])
+def test_recut_slabs_match_single_process(tmp_path, world, app, dims, iterate, exchange,
+                                          overlap):
+  """Slabs cut afresh every super-step: same cells as one process,
+  in both orders; the ranks' final rows tile the final valid range."""
+  meta = run_world(tmp_path, world, app, dims, iterate, exchange, overlap, recut=True)
+  st = frontend.load(os.path.join(SAMPLES, app + '.soda'), iterate=iterate)
+  spec = specmod.spec_from_stencil(st)
+  lo, hi = specmod.iteration_margins(spec, iterate)[-1]
+  assert meta[0][0] == lo[-1] and meta[-1][1] == dims[-1] - hi[-1]
+  for (a0, a1, _, _), (b0, b1, _, _) in zip(meta, meta[1:]):
+    assert a1 == b0
+  sizes = [a1 - a0 for a0, a1, _, _ in meta]
+  assert max(sizes) - min(sizes) <= 1
+
+
+def test_recut_plan_geometry():
+  # cfg4 on 8 ranks: every super-step's output rows cut evenly, rows change owner
+  plans = [sdist.RecutPlan([16384, 16384], r, 8, 1, 1, 144, 1000) for r in range(8)]
+  p = plans[0]
+  assert [s for s in p.steps] == [(144 * i, min(144, 1000 - 144 * i)) for i in range(7)]
+  assert p.owned[0] == sdist.slab_bounds(16384, 8)
+  assert p.cuts[0][0] == 144 and p.cuts[0][-1] == 16384 - 144
+  assert p.final[0][0] == 1000 and p.final[-1][1] == 15384
+  for s in range(len(p.steps)):
+    widths = [b - a for a, b in zip(p.cuts[s], p.cuts[s][1:])]
+    assert max(widths) - min(widths) <= 1
+    # what one rank sends is what the other receives
+    for r in range(8):
+      sends, recvs = plans[r].messages(s)
+      for q, rows in sends:
+        assert (r, rows) in plans[q].messages(s)[1]
+      for q, rows in recvs:
+        assert (r, rows) in plans[q].messages(s)[0]
+      # own rows + received rows cover exactly what the rank reads
+      need = plans[r].need[s][r]
+      got = sorted([plans[r].owned[s][r]] + [rows for _, rows in recvs])
+      covered = need[0]
+      for a, b in got:
+        if b <= covered or a > covered:
+          continue
+        covered = max(covered, b)
+      assert covered >= need[1]
+  # every rank's arrays hold everything it ever reads
+  for q in plans:
+    for n in q.need:
+      a, b = q.local(n[q.rank])
+      assert 0 <= a < b <= q.local_extent
+    assert q.ghost_lo >= 0 and q.ghost_lo + q.own <= q.local_extent
+  # the busiest rank's rows per iteration: 93.9 % of an even share with ghost rows
+  # against 87.8 % for the static cut (DESIGN.md 7)
+  ideal = sum(16384 - 2 * k for k in range(1, 1001)) / 8.0
+  assert 0.93 < ideal / p.max_rows_per_iteration() < 0.95
+  # cfg5 on 8 ranks: the static cut idles the edge ranks after iteration 64
+  q = sdist.RecutPlan([512, 512, 512], 0, 8, 1, 1, 4, 200)
+  ideal = sum(512 - 2 * k for k in range(1, 201)) / 8.0
+  assert ideal / q.max_rows_per_iteration() > 0.93
+  assert q.final[0] == (200, 214) and q.final[7] == (298, 312)
+  # bands: the rows other ranks read next, the interior the rest
+  mid = plans[3]
+  bands, interior = mid.pieces(0)
+  lo, hi = mid.cuts[0][3], mid.cuts[0][4]
+  assert bands[0][0] == lo and bands[-1][1] == hi and interior == (bands[0][1], bands[1][0])
+  assert bands[0][1] == mid.need[1][2][1] and bands[1][0] == mid.need[1][4][0]
+  assert mid.pieces(len(mid.steps) - 1) is None
+  # one rank: no messages, one piece
+  solo = sdist.RecutPlan([64, 48], 0, 1, 1, 1, 4, 10)
+  assert solo.messages(0) == ([], []) and solo.pieces(0) is None
+  assert solo.local_extent == 48 and solo.final_rows == (10, 38)
 
 
 def test_slab_bounds_and_plan():
