@@ -68,6 +68,11 @@ def parse_args():
                   help='N > 1: keep the default exchange period and the serial order '
                        'instead of timing the candidate (period, order) pairs during '
                        'warm-up')
+  ap.add_argument('--static-cut', action='store_true',
+                  help='N > 1: every rank keeps the rows of the even cut of the whole grid '
+                       'for the whole run; default: the rows each super-step defines are cut '
+                       'evenly again (the valid box shrinks every iteration: a static cut '
+                       'idles the first and last ranks)')
   ap.add_argument('--no-tune', action='store_true',
                   help='split `iterate` into fused depths by the calibrated model alone '
                        'instead of timing the candidate splits on this grid during '
@@ -475,6 +480,12 @@ def measure(app, dims, iterate, steps, warmup, max_depth=0, split='', no_tune=Fa
                   depth_split='given (--split)' if split else
                   'measured (soda_hip_plan_tune)' if not no_tune and
                   iterate > 1 else 'calibrated model',
+                  # chunk length and workgroups per CU of the memory-bound launches: the
+                  # kernels' calibration records, or a pair the tuning step measured to
+                  # beat them on this device
+                  stream_chunk_choice='calibrated' if no_tune else
+                  'measured (%d kernel x box)' % program.tuned_streams()
+                  if program.tuned_streams() else 'calibrated (confirmed by measurement)',
                   effective_GBps=valid * abytes / (wall / steps) / 1e9,
                   device=host.device_info(0)['arch']),
       roofline=roofline_block(spec, program, schedule,

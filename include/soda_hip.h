@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SODA_HIP_ABI_VERSION 7
+#define SODA_HIP_ABI_VERSION 8
 #define SODA_HIP_MAX_DIMS 4
 #define SODA_HIP_MAX_TENSORS 16 /* inputs + stages of one program */
 #define SODA_HIP_MAX_IO 8
@@ -348,6 +348,12 @@ int soda_hip_plan_set_split(soda_hip_plan* plan, const int64_t dims[SODA_HIP_MAX
  * reach into rows another piece has already finished. */
 int soda_hip_plan_set_out_final_only(soda_hip_plan* plan, int on);
 
+/* *n = how many (kernel, box) pairs of the plan run a (chunk length, workgroups per CU)
+ * that soda_hip_plan_tune MEASURED to beat the kernel's calibrated pair on this device by
+ * more than 1 % (0: every streaming launch runs its calibration record).  For bench
+ * lines: which of the two a timed run used (ABI 8). */
+int soda_hip_plan_tuned_streams(const soda_hip_plan* plan, int* n);
+
 /* ---- shader clock under load ------------------------------------------------
  * The deep kernels are bound by VALU issue, and the clock the chip holds under their
  * load (2.0-2.2 of 2.4 GHz) is one of the factors between their rate and the peak's
@@ -375,7 +381,7 @@ int soda_hip_clock_probe_finish(soda_hip_plan* plan, double* shader_ghz, double*
  * driver, covered by world-size 2 and 3 tests); this entry exists so that a C or
  * C++ caller - the generated `<app>()` - can shard without Python.  librccl.so is
  * loaded on first use.  Tested with world == 1 on the real library and with world
- * 2 and 3 over a test-only stand-in for librccl.so (ranks = host threads sharing one
+ * 2 to 4 over a test-only stand-in for librccl.so (ranks = host threads sharing one
  * GPU, tests/rccl_standin): every line below the ABI runs; what has NOT run yet is
  * real RCCL with more than one rank (no multi-GPU box was available). */
 typedef struct soda_hip_slab {
@@ -385,10 +391,34 @@ typedef struct soda_hip_slab {
                                  (soda_hip_plan_margins(plan, 1)) */
   int32_t exchange;           /* iterations between ghost exchanges (>= 1) */
   int64_t dims[SODA_HIP_MAX_DIMS]; /* the GLOBAL grid */
-  int64_t own_first, own_last;     /* this rank's rows of the outermost dimension */
+  int64_t own_first, own_last;     /* this rank's rows of the outermost dimension: the
+                                      rows of the INPUT it is handed (with
+                                      SODA_HIP_SLAB_CUT_RECUT: of the even cut,
+                                      rank * rows / world rounded as soda_hip_slab_layout
+                                      documents) */
   int32_t order;                   /* SODA_HIP_SLAB_SERIAL or SODA_HIP_SLAB_BANDS_FIRST (ABI 7) */
+  int32_t cut;                     /* SODA_HIP_SLAB_CUT_STATIC or _RECUT (ABI 8) */
+  int32_t abort_on_error;          /* see soda_hip_run_slab, "Failure" (ABI 8) */
   int32_t reserved;                /* 0 */
 } soda_hip_slab;
+
+/* Who owns which rows when (ABI 8).
+ *   CUT_STATIC  every rank keeps [own_first, own_last) for the whole run and
+ *               `exchange * reach` ghost rows beside them.  The valid box shrinks by the
+ *               reach every iteration (core.py:794-835), so the first and last ranks run
+ *               out of work while the middle ones keep full slabs: a step costs what the
+ *               busiest rank costs - jacobi2d 16384^2 x1000 on 8 ranks 87.8 % of an even
+ *               share (ghost rows included), jacobi3d 512^3 x200 on 8 ranks 58 %.
+ *   CUT_RECUT   every super-step cuts the rows its OUTPUT level defines,
+ *               [(done + step) reach_lo, rows - (done + step) reach_hi), evenly again
+ *               (93.9 % and 93.7 % for the two runs above); a rank reads its output rows
+ *               widened by step x reach, and what it does not hold of those - ghost rows
+ *               and rows that changed owner alike - arrives in the super-step's one group
+ *               of sends and receives, from whichever ranks hold it (with thin slabs not
+ *               only the neighbours).  Same logic as soda_hip/runtime/dist.py: RecutPlan.
+ *               The arrays span everything the rank ever holds (soda_hip_slab_layout). */
+#define SODA_HIP_SLAB_CUT_STATIC 0
+#define SODA_HIP_SLAB_CUT_RECUT 1
 
 /* How soda_hip_run_slab orders a super-step's exchange against its sweeps (the same two
  * orders as soda_hip/runtime/dist.py: SerialSchedule / StreamSchedule):
@@ -414,21 +444,51 @@ typedef struct soda_hip_slab {
 int soda_hip_slab_exchange(int64_t rows, int world, int reach_lo, int reach_hi,
                            int wanted, int* exchange);
 
-/* extents of the rank's local arrays (own rows + ghost rows) and the ghost depths */
+/* extents of the rank's local arrays (own rows + ghost rows) and the ghost depths
+ * (CUT_STATIC only: a re-cut run's arrays depend on the iteration count,
+ * soda_hip_slab_layout) */
 int soda_hip_slab_extent(const soda_hip_plan* plan, const soda_hip_slab* slab,
                          int64_t local_dims[SODA_HIP_MAX_DIMS], int64_t* ghost_lo,
                          int64_t* ghost_hi);
 
-/* a: level-0 slab (own rows at [ghost_lo, ghost_lo + own), ghost rows anything),
- * never written except for its ghost rows; b, c: two more arrays of the same
+/* Where a run of `iterate` iterations keeps its rows, for either cut (ABI 8):
+ *   local_dims     extents of the three arrays a, b, c;
+ *   *input_offset  row of the arrays at which the rank's rows of the input,
+ *                  [own_first, own_last), go (array `a`);
+ *   *result_first, *result_last  the GLOBAL rows of the result the rank holds afterwards
+ *                  (CUT_STATIC: its own rows; CUT_RECUT: its share of the even cut of the
+ *                  rows still valid after `iterate` iterations - possibly none);
+ *   *result_offset the row of the result array at which they start.
+ * CUT_RECUT requires own_first / own_last to be the even cut of the whole grid:
+ * rank r owns rows [r * base + min(r, extra), ... + base + (r < extra)), base = rows /
+ * world, extra = rows % world - every rank derives every other rank's rows from it. */
+int soda_hip_slab_layout(const soda_hip_plan* plan, const soda_hip_slab* slab, int iterate,
+                         int64_t local_dims[SODA_HIP_MAX_DIMS], int64_t* input_offset,
+                         int64_t* result_first, int64_t* result_last,
+                         int64_t* result_offset);
+
+/* a: level-0 slab (own rows at the layout's input offset, every other row anything),
+ * never written except for the rows it receives; b, c: two more arrays of the same
  * size.  comm: an ncclComm_t of `world` ranks (NULL when world == 1).  *result
- * receives b or c, whichever holds the rank's own rows after `iterate`
- * iterations.  Asynchronous on `stream`.
- * Failure: a rank that fails here (a launch, an allocation, an RCCL error, a bad
- * descriptor) would leave its neighbours blocked in ncclRecv, so with world > 1 ANY error
- * return means the communicator has been aborted (ncclCommAbort) first: the peers'
- * pending and later operations on it fail, their calls return an error as well, and
- * `comm` must not be used again (nor aborted or destroyed a second time). */
+ * receives b or c, whichever holds the rank's rows of the result after `iterate`
+ * iterations (soda_hip_slab_layout says which rows and where).  Asynchronous on `stream`.
+ * Failure: the descriptor, `iterate`, the order and the cut are checked before anything
+ * is sent; such an error leaves the communicator alone and usable.  Later failures (a
+ * launch, an allocation, an RCCL error) happen while peers may be waiting in ncclRecv
+ * for rows this rank will not send any more:
+ *   abort_on_error == 0  the error is returned and the communicator left to the caller -
+ *     for a caller that drives every rank of the node from one process (the generated
+ *     `<app>_multi_gpu`: the thread that sees the error aborts EVERY rank's communicator,
+ *     once, which is what unblocks the peers);
+ *   abort_on_error != 0  after a failure of this rank's own (anything but an error RCCL
+ *     itself reports: that may be the caller's watchdog, or a peer's driver, having aborted
+ *     this very communicator - it is then left as it is) this rank's communicator is
+ *     aborted (ncclCommAbort) before the error is returned, the error text ends in
+ *     "(communicator aborted)", and it must not be used, aborted or destroyed again.  Best effort:
+ *     ncclCommAbort is LOCAL to the calling rank - it releases this rank's resources and
+ *     fails its own pending operations, it does not wake a peer that spins in an enqueued
+ *     receive.  A one-process-per-rank caller still has to watch ncclCommGetAsyncError
+ *     (or a timeout) on every rank and abort there too. */
 int soda_hip_run_slab(soda_hip_plan* plan, const soda_hip_slab* slab, void* comm,
                       void* a, void* b, void* c, int iterate, void* stream,
                       void** result, int* exchanges);

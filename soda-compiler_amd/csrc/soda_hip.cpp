@@ -1538,8 +1538,10 @@ int soda_hip_clock_probe_start(soda_hip_plan* plan, int spins) {
                 "before ABI 7)");
   }
   if (!plan->side &&
-      hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) != hipSuccess)
+      hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) != hipSuccess) {
+    plan->side = nullptr;
     return fail(SODA_HIP_ERR_DEVICE_RUN, "hipStreamCreate failed");
+  }
   if (!plan->probe_buf) HIP_TRY(SODA_HIP_ERR_DEVICE_MALLOC, hipMalloc(&plan->probe_buf, 16));
   HIP_TRY(SODA_HIP_ERR_DEVICE_RUN, hipMemsetAsync(plan->probe_buf, 0, 16, plan->side));
   struct { void* out; int spins; } args = {plan->probe_buf, spins};
@@ -1548,9 +1550,14 @@ int soda_hip_clock_probe_start(soda_hip_plan* plan, int spins) {
                     &size, HIP_LAUNCH_PARAM_END};
   // the wall time of the probe comes from events around it (the realtime counter it
   // reads is nominally 100 MHz; measured against events it is what calibrates it)
-  if (!plan->probe_t0 && (hipEventCreate(&plan->probe_t0) != hipSuccess ||
-                          hipEventCreate(&plan->probe_t1) != hipSuccess))
+  if (!plan->probe_t0 && hipEventCreate(&plan->probe_t0) != hipSuccess) {
+    plan->probe_t0 = nullptr;
     return fail(SODA_HIP_ERR_DEVICE_RUN, "hipEventCreate failed");
+  }
+  if (!plan->probe_t1 && hipEventCreate(&plan->probe_t1) != hipSuccess) {
+    plan->probe_t1 = nullptr;
+    return fail(SODA_HIP_ERR_DEVICE_RUN, "hipEventCreate failed");
+  }
   HIP_TRY(SODA_HIP_ERR_DEVICE_RUN, hipEventRecord(plan->probe_t0, plan->side));
   HIP_TRY(SODA_HIP_ERR_DEVICE_RUN,
           hipModuleLaunchKernel(plan->probe, 1, 1, 1, 64, 1, 1, 0, plan->side, nullptr, config));
@@ -1648,6 +1655,118 @@ int slab_geometry(const soda_hip_plan* plan, const soda_hip_slab* s, SlabGeometr
   return 0;
 }
 
+// ---- slabs re-cut to the shrinking valid box (runtime/dist.py: RecutPlan) ----
+struct Rows {
+  int64_t lo = 0, hi = 0;
+  bool empty() const { return hi <= lo; }
+};
+
+Rows intersect(const Rows& a, const Rows& b) {
+  Rows r;
+  r.lo = std::max(a.lo, b.lo);
+  r.hi = std::min(a.hi, b.hi);
+  return r;
+}
+
+// world + 1 cut points of [lo, hi): as even as possible, the longer shares first
+std::vector<int64_t> even_cut(int64_t lo, int64_t hi, int world) {
+  const int64_t extent = std::max<int64_t>(0, hi - lo);
+  const int64_t base = extent / world, extra = extent % world;
+  std::vector<int64_t> pts(world + 1, lo);
+  for (int r = 0; r < world; ++r) pts[r + 1] = pts[r] + base + (r < extra ? 1 : 0);
+  return pts;
+}
+
+struct RecutStep {
+  int done = 0, step = 0;
+  std::vector<Rows> owned;      // per rank: rows of the INPUT level it holds
+  std::vector<int64_t> cuts;    // world + 1 cut points of the OUTPUT level's rows
+  std::vector<Rows> need;       // per rank: rows of the input level it reads (empty: none)
+};
+
+struct RecutTable {
+  std::vector<RecutStep> steps;
+  std::vector<Rows> final;      // per rank: rows of the result
+  int64_t base = 0, extent = 0; // this rank's arrays span global rows [base, base + extent)
+  int64_t row_bytes = 0;
+};
+
+int recut_table(const soda_hip_plan* plan, const soda_hip_slab* s, int iterate, RecutTable* t) {
+  const soda_hip_program& p = plan->prog;
+  if (p.n_inputs != 1 || p.n_outputs != 1)
+    return fail(SODA_HIP_ERR_CONSTRAINT, "slabs: one-input one-output programs");
+  if (s->world < 1 || s->rank < 0 || s->rank >= s->world || s->exchange < 1 ||
+      s->reach_lo < 0 || s->reach_hi < 0 || iterate < 1)
+    return fail(SODA_HIP_ERR_CONSTRAINT, "slab descriptor out of range");
+  const int64_t rows = s->dims[p.dim - 1];
+  if (rows < 1) return fail(SODA_HIP_ERR_CONSTRAINT, "slab descriptor: %lld rows", (long long)rows);
+  const std::vector<int64_t> level0 = even_cut(0, rows, s->world);
+  if (s->own_first != level0[s->rank] || s->own_last != level0[s->rank + 1])
+    return fail(SODA_HIP_ERR_CONSTRAINT,
+                "re-cut slabs: rank %d of %d must be handed rows [%lld, %lld) of %lld (the even "
+                "cut), not [%lld, %lld)", s->rank, s->world, (long long)level0[s->rank],
+                (long long)level0[s->rank + 1], (long long)rows, (long long)s->own_first,
+                (long long)s->own_last);
+  std::vector<Rows> level(s->world);
+  for (int r = 0; r < s->world; ++r) { level[r].lo = level0[r]; level[r].hi = level0[r + 1]; }
+  t->steps.clear();
+  int64_t lo_hull = s->own_first, hi_hull = s->own_last;
+  for (int done = 0; done < iterate;) {
+    RecutStep st;
+    st.done = done;
+    st.step = std::min(s->exchange, iterate - done);
+    const int64_t lo = (int64_t)(done + st.step) * s->reach_lo;
+    const int64_t hi = rows - (int64_t)(done + st.step) * s->reach_hi;
+    st.cuts = even_cut(lo, std::max(lo, hi), s->world);
+    st.owned = level;
+    st.need.assign(s->world, Rows{});
+    for (int r = 0; r < s->world; ++r) {
+      if (st.cuts[r + 1] <= st.cuts[r]) continue;
+      st.need[r].lo = st.cuts[r] - (int64_t)st.step * s->reach_lo;
+      st.need[r].hi = st.cuts[r + 1] + (int64_t)st.step * s->reach_hi;
+    }
+    if (!st.need[s->rank].empty()) {
+      lo_hull = std::min(lo_hull, st.need[s->rank].lo);
+      hi_hull = std::max(hi_hull, st.need[s->rank].hi);
+    }
+    for (int r = 0; r < s->world; ++r) { level[r].lo = st.cuts[r]; level[r].hi = st.cuts[r + 1]; }
+    done += st.step;
+    t->steps.push_back(st);
+  }
+  t->final = level;
+  t->base = lo_hull;
+  t->extent = hi_hull - lo_hull;
+  t->row_bytes = p.elem_size[0];
+  for (int d = 0; d < p.dim - 1; ++d) t->row_bytes *= s->dims[d];
+  return 0;
+}
+
+// Super-step i, bands first (RecutPlan.pieces): the rows other ranks read in super-step
+// i + 1 come first, the interior afterwards.  false: nothing to gain (the last super-step,
+// no output rows, nobody waiting, or bands that meet).
+bool recut_pieces(const RecutTable& t, const soda_hip_slab* s, size_t i, std::vector<Rows>* bands,
+                  Rows* interior) {
+  if (i + 1 >= t.steps.size()) return false;
+  const RecutStep& st = t.steps[i];
+  const RecutStep& next = t.steps[i + 1];
+  const int64_t lo = st.cuts[s->rank], hi = st.cuts[s->rank + 1];
+  if (hi <= lo) return false;
+  int64_t b_lo = lo, b_hi = hi;
+  for (int q = 0; q < s->rank; ++q)
+    if (!next.need[q].empty() && next.need[q].hi > lo) b_lo = std::max(b_lo, next.need[q].hi);
+  for (int q = s->rank + 1; q < s->world; ++q)
+    if (!next.need[q].empty() && next.need[q].lo < hi) b_hi = std::min(b_hi, next.need[q].lo);
+  b_lo = std::min(b_lo, hi);
+  b_hi = std::max(b_hi, lo);
+  if ((b_lo == lo && b_hi == hi) || b_lo >= b_hi) return false;
+  bands->clear();
+  if (b_lo > lo) bands->push_back(Rows{lo, b_lo});
+  if (b_hi < hi) bands->push_back(Rows{b_hi, hi});
+  interior->lo = b_lo;
+  interior->hi = b_hi;
+  return true;
+}
+
 }  // namespace
 
 int soda_hip_slab_exchange(int64_t rows, int world, int reach_lo, int reach_hi,
@@ -1671,6 +1790,9 @@ int soda_hip_slab_extent(const soda_hip_plan* plan, const soda_hip_slab* slab,
                          int64_t local_dims[SODA_HIP_MAX_DIMS], int64_t* ghost_lo,
                          int64_t* ghost_hi) {
   if (!plan || !slab || !local_dims) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  if (slab->cut != SODA_HIP_SLAB_CUT_STATIC)
+    return fail(SODA_HIP_ERR_CONSTRAINT, "soda_hip_slab_extent describes the static cut; a "
+                "re-cut run's arrays depend on the iteration count: soda_hip_slab_layout");
   SlabGeometry g;
   int rc = slab_geometry(plan, slab, &g);
   if (rc) return rc;
@@ -1679,6 +1801,37 @@ int soda_hip_slab_extent(const soda_hip_plan* plan, const soda_hip_slab* slab,
   local_dims[plan->prog.dim - 1] = g.extent;
   if (ghost_lo) *ghost_lo = g.ghost_lo;
   if (ghost_hi) *ghost_hi = g.ghost_hi;
+  return 0;
+}
+
+int soda_hip_slab_layout(const soda_hip_plan* plan, const soda_hip_slab* slab, int iterate,
+                         int64_t local_dims[SODA_HIP_MAX_DIMS], int64_t* input_offset,
+                         int64_t* result_first, int64_t* result_last,
+                         int64_t* result_offset) {
+  if (!plan || !slab || !local_dims) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  if (slab->cut != SODA_HIP_SLAB_CUT_STATIC && slab->cut != SODA_HIP_SLAB_CUT_RECUT)
+    return fail(SODA_HIP_ERR_CONSTRAINT, "slab cut %d", (int)slab->cut);
+  for (int d = 0; d < SODA_HIP_MAX_DIMS; ++d)
+    local_dims[d] = d < plan->prog.dim ? slab->dims[d] : 1;
+  if (slab->cut == SODA_HIP_SLAB_CUT_STATIC) {
+    SlabGeometry g;
+    int rc = slab_geometry(plan, slab, &g);
+    if (rc) return rc;
+    local_dims[plan->prog.dim - 1] = g.extent;
+    if (input_offset) *input_offset = g.ghost_lo;
+    if (result_first) *result_first = slab->own_first;
+    if (result_last) *result_last = slab->own_last;
+    if (result_offset) *result_offset = g.ghost_lo;
+    return 0;
+  }
+  RecutTable t;
+  int rc = recut_table(plan, slab, iterate, &t);
+  if (rc) return rc;
+  local_dims[plan->prog.dim - 1] = t.extent;
+  if (input_offset) *input_offset = slab->own_first - t.base;
+  if (result_first) *result_first = t.final[slab->rank].lo;
+  if (result_last) *result_last = t.final[slab->rank].hi;
+  if (result_offset) *result_offset = t.final[slab->rank].lo - t.base;
   return 0;
 }
 
@@ -1691,77 +1844,130 @@ int soda_hip_run_slab(soda_hip_plan* plan, const soda_hip_slab* slab, void* comm
     return fail(SODA_HIP_ERR_NULL_ARGUMENT, "world %d needs an RCCL communicator", slab->world);
   if (slab->world > 1 && !rccl().ok)
     return fail(SODA_HIP_ERR_NO_DEVICE, "librccl.so could not be loaded: %s", dlerror());
-  // From here on a failure of THIS rank would leave its neighbours blocked in ncclRecv
-  // (they wait for rows this rank will never send): whatever fails below, the
-  // communicator is aborted before the error is returned - every peer's pending and
-  // later operation on it then fails instead of waiting - and is invalid afterwards.
+  // Everything that can be wrong with the call itself is found before the first message
+  // is enqueued: such an error leaves the communicator alone (the peers have not been
+  // promised anything yet - the caller's own rendezvous, or its next call, sees it).
+  if (iterate < 1) return fail(SODA_HIP_ERR_CONSTRAINT, "iterate must be >= 1");
+  if (slab->order != SODA_HIP_SLAB_SERIAL && slab->order != SODA_HIP_SLAB_BANDS_FIRST)
+    return fail(SODA_HIP_ERR_CONSTRAINT, "slab order %d", (int)slab->order);
+  if (slab->cut != SODA_HIP_SLAB_CUT_STATIC && slab->cut != SODA_HIP_SLAB_CUT_RECUT)
+    return fail(SODA_HIP_ERR_CONSTRAINT, "slab cut %d", (int)slab->cut);
+  SlabGeometry g{};
+  RecutTable table;
+  const bool recut = slab->cut == SODA_HIP_SLAB_CUT_RECUT;
+  int rc = recut ? recut_table(plan, slab, iterate, &table) : slab_geometry(plan, slab, &g);
+  if (rc) return rc;
+  const bool overlapped = slab->order == SODA_HIP_SLAB_BANDS_FIRST && slab->world > 1;
+  if (overlapped) {
+    // the stream and the two events of the bands-first order, each under its own check (the
+    // clock probe creates the same stream; a half-built set must be completed, not skipped)
+    if (!plan->side && hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) != hipSuccess) {
+      plan->side = nullptr;
+      return fail(SODA_HIP_ERR_DEVICE_RUN, "side stream for the exchange: %s",
+                  hipGetErrorString(hipGetLastError()));
+    }
+    if (!plan->ev_main &&
+        hipEventCreateWithFlags(&plan->ev_main, hipEventDisableTiming) != hipSuccess) {
+      plan->ev_main = nullptr;
+      return fail(SODA_HIP_ERR_DEVICE_RUN, "event for the exchange stream: %s",
+                  hipGetErrorString(hipGetLastError()));
+    }
+    if (!plan->ev_landed &&
+        hipEventCreateWithFlags(&plan->ev_landed, hipEventDisableTiming) != hipSuccess) {
+      plan->ev_landed = nullptr;
+      return fail(SODA_HIP_ERR_DEVICE_RUN, "event for the exchange stream: %s",
+                  hipGetErrorString(hipGetLastError()));
+    }
+  }
+  // From here on a failure of THIS rank may leave peers waiting in ncclRecv for rows it
+  // will never send.  abort_on_error: after a failure of this rank's OWN (a launch, an
+  // allocation - not an error RCCL reports, which may be somebody's abort of this very
+  // communicator) the communicator is aborted before the error is returned (best effort -
+  // ncclCommAbort is local to the rank, include/soda_hip.h); otherwise the communicator
+  // is the caller's to abort, for every rank of its process.
+  bool rccl_failed = false;     // the error came from RCCL itself (e.g. an aborted communicator)
   auto give_up = [&](int rc) {
-    if (rc && slab->world > 1 && comm && rccl().comm_abort) {
+    if (rc && !rccl_failed && slab->abort_on_error && slab->world > 1 && comm &&
+        rccl().comm_abort) {
       const std::string keep = g_last_error;
       (void)rccl().comm_abort(comm);
       g_last_error = keep + " (communicator aborted)";
     }
     return rc;
   };
-  if (iterate < 1) return give_up(fail(SODA_HIP_ERR_CONSTRAINT, "iterate must be >= 1"));
-  if (slab->order != SODA_HIP_SLAB_SERIAL && slab->order != SODA_HIP_SLAB_BANDS_FIRST)
-    return give_up(fail(SODA_HIP_ERR_CONSTRAINT, "slab order %d", (int)slab->order));
-  SlabGeometry g;
-  int rc = slab_geometry(plan, slab, &g);
-  if (rc) return give_up(rc);
   const soda_hip_program& p = plan->prog;
   const int last = p.dim - 1;
   hipStream_t s = as_stream(stream);
   int64_t local_dims[SODA_HIP_MAX_DIMS] = {1, 1, 1, 1};
   for (int d = 0; d < p.dim; ++d) local_dims[d] = slab->dims[d];
-  local_dims[last] = g.extent;
-  const int64_t send_down = g.has_lo ? (int64_t)slab->exchange * slab->reach_hi : 0;
-  const int64_t send_up = g.has_hi ? (int64_t)slab->exchange * slab->reach_lo : 0;
-  auto exchange_ghosts = [&](char* array, hipStream_t on) -> int {
-    if (slab->world == 1) return 0;
-    const Rccl& r = rccl();
-    char* first_own = array + g.ghost_lo * g.row_bytes;
-    char* last_own = first_own + g.own * g.row_bytes;
-    int e = r.group_start();
+  local_dims[last] = recut ? table.extent : g.extent;
+  const int64_t row_bytes = recut ? table.row_bytes : g.row_bytes;
+  const int64_t send_down = !recut && g.has_lo ? (int64_t)slab->exchange * slab->reach_hi : 0;
+  const int64_t send_up = !recut && g.has_hi ? (int64_t)slab->exchange * slab->reach_lo : 0;
+  // one message = rows [first, first + rows) of the LOCAL array, to or from a peer
+  struct Message { bool send; int peer; int64_t first, rows; };
+  auto static_messages = [&]() {
+    std::vector<Message> m;
+    const int64_t first_own = g.ghost_lo, last_own = g.ghost_lo + g.own;
     // lower neighbour: it needs our first rows, we need its last ones
-    if (!e && g.has_lo && send_down)
-      e = r.send(first_own, (size_t)(send_down * g.row_bytes), 0, slab->rank - 1, comm, on);
-    if (!e && g.has_lo && g.ghost_lo)
-      e = r.recv(array, (size_t)(g.ghost_lo * g.row_bytes), 0, slab->rank - 1, comm, on);
-    if (!e && g.has_hi && send_up)
-      e = r.send(last_own - send_up * g.row_bytes, (size_t)(send_up * g.row_bytes), 0,
-                 slab->rank + 1, comm, on);
-    if (!e && g.has_hi && g.ghost_hi)
-      e = r.recv(last_own, (size_t)(g.ghost_hi * g.row_bytes), 0, slab->rank + 1, comm, on);
+    if (g.has_lo && send_down) m.push_back({true, slab->rank - 1, first_own, send_down});
+    if (g.has_lo && g.ghost_lo) m.push_back({false, slab->rank - 1, 0, g.ghost_lo});
+    if (g.has_hi && send_up) m.push_back({true, slab->rank + 1, last_own - send_up, send_up});
+    if (g.has_hi && g.ghost_hi) m.push_back({false, slab->rank + 1, last_own, g.ghost_hi});
+    return m;
+  };
+  // before super-step i of a re-cut run: to every rank the rows it reads and we hold, from
+  // every rank the rows we read and it holds - ghost rows and rows changing owner alike
+  // (both sides derive a pair's rows from the same table; ascending peers, sends first)
+  auto recut_messages = [&](size_t i) {
+    std::vector<Message> m;
+    const RecutStep& st = table.steps[i];
+    const Rows& mine = st.owned[slab->rank];
+    for (int pass = 0; pass < 2; ++pass)
+      for (int q = 0; q < slab->world; ++q) {
+        if (q == slab->rank) continue;
+        const Rows rows = pass == 0 ? intersect(st.need[q], mine)
+                                    : intersect(st.need[slab->rank], st.owned[q]);
+        const bool wanted = pass == 0 ? !st.need[q].empty() && !mine.empty()
+                                      : !st.need[slab->rank].empty() && !st.owned[q].empty();
+        if (wanted && !rows.empty())
+          m.push_back({pass == 0, q, rows.lo - table.base, rows.hi - rows.lo});
+      }
+    return m;
+  };
+  auto exchange_rows = [&](char* array, const std::vector<Message>& messages,
+                           hipStream_t on) -> int {
+    if (slab->world == 1 || messages.empty()) return 0;
+    const Rccl& r = rccl();
+    int e = r.group_start();
+    for (const Message& m : messages) {
+      if (e) break;
+      char* at = array + m.first * row_bytes;
+      e = m.send ? r.send(at, (size_t)(m.rows * row_bytes), 0, m.peer, comm, on)
+                 : r.recv(at, (size_t)(m.rows * row_bytes), 0, m.peer, comm, on);
+    }
     const int e2 = r.group_end();
-    if (e || e2)
+    if (e || e2) {
+      rccl_failed = true;
       return fail(SODA_HIP_ERR_DEVICE_RUN, "RCCL ghost exchange failed: %s",
                   r.error_string ? r.error_string(e ? e : e2) : "?");
+    }
     return 0;
   };
-  // Bands-first order (runtime/dist.py: run_slab with a StreamSchedule, the same
-  // band_plan): every super-step but the last first sweeps the two bands of rows its
-  // neighbours are waiting for, hands them to the exchange of the NEXT super-step on a
-  // stream the plan owns, and sweeps the interior meanwhile.  A piece's intermediate
-  // launches must not write rows of `dst` another piece has finished (they are being
-  // sent): pieces run with out_final_only.
-  const bool overlapped = slab->order == SODA_HIP_SLAB_BANDS_FIRST && slab->world > 1;
-  if (overlapped && !plan->side) {
-    if (hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&plan->ev_main, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&plan->ev_landed, hipEventDisableTiming) != hipSuccess)
-      return give_up(fail(SODA_HIP_ERR_DEVICE_RUN, "side stream for the exchange: %s",
-                          hipGetErrorString(hipGetLastError())));
-  }
+  // Bands-first order (runtime/dist.py: StreamSchedule; band_plan / RecutPlan.pieces):
+  // every super-step but the last first sweeps the bands of rows other ranks are waiting
+  // for, hands them to the exchange of the NEXT super-step on a stream the plan owns, and
+  // sweeps the interior meanwhile.  A piece's intermediate launches must not write rows of
+  // `dst` another piece has finished (they are being sent): pieces run with out_final_only.
   bool landed_pending = false;      // an exchange on the side stream main has not waited for
-  auto exchange = [&](char* array) -> int {
-    if (!overlapped) return exchange_ghosts(array, s);
+  auto exchange = [&](char* array, const std::vector<Message>& messages) -> int {
+    if (!overlapped) return exchange_rows(array, messages, s);
     // the rows to be sent were produced on the main stream: the side stream follows
     // everything enqueued there so far
     if (hipEventRecord(plan->ev_main, s) != hipSuccess ||
         hipStreamWaitEvent(plan->side, plan->ev_main, 0) != hipSuccess)
       return fail(SODA_HIP_ERR_DEVICE_RUN, "ordering the exchange stream failed");
-    int e = exchange_ghosts(array, plan->side);
+    int e = exchange_rows(array, messages, plan->side);
     if (e) return e;
     if (hipEventRecord(plan->ev_landed, plan->side) != hipSuccess)
       return fail(SODA_HIP_ERR_DEVICE_RUN, "hipEventRecord failed");
@@ -1784,21 +1990,36 @@ int soda_hip_run_slab(soda_hip_plan* plan, const soda_hip_slab* slab, void* comm
   void* cycle[2] = {b, c};
   int done = 0, k = 0, count = 0;
   bool pending = false;            // src's ghost rows are (being) filled already
+  // the sub-array of local rows [r0, r1) swept `step` iterations with the given outer
+  // margins (0 = the side is cut inside valid rows)
+  auto sweep_rows = [&](void* from, void* to, int64_t r0, int64_t r1, int step,
+                        const int32_t* lo, const int32_t* hi, bool final_only) -> int {
+    int64_t dims_piece[SODA_HIP_MAX_DIMS];
+    for (int d = 0; d < SODA_HIP_MAX_DIMS; ++d) dims_piece[d] = local_dims[d];
+    dims_piece[last] = r1 - r0;
+    void* sp = (char*)from + r0 * row_bytes;
+    void* dp = (char*)to + r0 * row_bytes;
+    plan->out_final_only = final_only ? true : was_final_only;
+    const int e = soda_hip_sweep(plan, &sp, &dp, dims_piece, step, lo, hi, stream);
+    plan->out_final_only = was_final_only;
+    return e;
+  };
   while (done < iterate && !rc) {
     if (!pending) {
-      rc = exchange((char*)src);
+      rc = exchange((char*)src, recut ? recut_messages((size_t)k) : static_messages());
       count += slab->world > 1;
     }
     if (!rc) rc = ghosts_have_landed();
     if (rc) break;
     pending = false;
     const int step = std::min(slab->exchange, iterate - done);
-    // valid region of the slab's input: ghost sides are fully valid, the global
-    // sides carry the margin of the iterations done so far
+    // valid region of the slab's input: sides cut inside valid rows are fully valid, the
+    // global sides of a static slab carry the margin of the iterations done so far (a
+    // re-cut rank's sub-array starts and ends at rows that are valid: every side is cut)
     int32_t lo[SODA_HIP_MAX_DIMS], hi[SODA_HIP_MAX_DIMS];
     output_margins(plan, done, lo, hi);
-    if (g.has_lo) lo[last] = 0;
-    if (g.has_hi) hi[last] = 0;
+    if (recut || g.has_lo) lo[last] = 0;
+    if (recut || g.has_hi) hi[last] = 0;
     void* dst = cycle[k % 2];
     if (slab->rank == fail_rank && k == fail_at) {
       rc = fail(SODA_HIP_ERR_DEVICE_RUN, "injected failure of rank %d at super-step %d",
@@ -1806,8 +2027,30 @@ int soda_hip_run_slab(soda_hip_plan* plan, const soda_hip_slab* slab, void* comm
       break;
     }
     const bool more = done + step < iterate;
-    const bool small = g.own < 2 * (send_down + send_up) + 1;
-    if (overlapped && more && !small) {
+    if (recut) {
+      const RecutStep& st = table.steps[(size_t)k];
+      const int64_t reach_lo = (int64_t)step * slab->reach_lo,
+                    reach_hi = (int64_t)step * slab->reach_hi;
+      auto piece = [&](const Rows& out, bool final_only) -> int {
+        return sweep_rows(src, dst, out.lo - reach_lo - table.base, out.hi + reach_hi - table.base,
+                          step, lo, hi, final_only);
+      };
+      std::vector<Rows> bands;
+      Rows interior;
+      const Rows out{st.cuts[slab->rank], st.cuts[slab->rank + 1]};
+      if (overlapped && recut_pieces(table, slab, (size_t)k, &bands, &interior)) {
+        for (const Rows& band : bands)
+          if (!rc) rc = piece(band, true);
+        if (!rc) {
+          rc = exchange((char*)dst, recut_messages((size_t)k + 1));   // beside the interior
+          count += 1;
+          pending = true;
+        }
+        if (!rc) rc = piece(interior, true);
+      } else if (!out.empty()) {
+        rc = piece(out, false);
+      }
+    } else if (overlapped && more && !(g.own < 2 * (send_down + send_up) + 1)) {
       const int64_t first_own = g.ghost_lo, last_own = g.ghost_lo + g.own;
       const int64_t reach_lo = (int64_t)step * slab->reach_lo,
                     reach_hi = (int64_t)step * slab->reach_hi;
@@ -1816,15 +2059,7 @@ int soda_hip_run_slab(soda_hip_plan* plan, const soda_hip_slab* slab, void* comm
         for (int d = 0; d < SODA_HIP_MAX_DIMS; ++d) { plo[d] = lo[d]; phi[d] = hi[d]; }
         if (cut_lo) plo[last] = 0;
         if (cut_hi) phi[last] = 0;
-        int64_t dims_piece[SODA_HIP_MAX_DIMS];
-        for (int d = 0; d < SODA_HIP_MAX_DIMS; ++d) dims_piece[d] = local_dims[d];
-        dims_piece[last] = r1 - r0;
-        void* sp = (char*)src + r0 * g.row_bytes;
-        void* dp = (char*)dst + r0 * g.row_bytes;
-        plan->out_final_only = true;
-        const int e = soda_hip_sweep(plan, &sp, &dp, dims_piece, step, plo, phi, stream);
-        plan->out_final_only = was_final_only;
-        return e;
+        return sweep_rows(src, dst, r0, r1, step, plo, phi, true);
       };
       int64_t lo_edge = first_own, hi_edge = last_own;
       if (g.has_lo) {    // the lower neighbour's ghost rows: our first send_down rows
@@ -1836,7 +2071,7 @@ int soda_hip_run_slab(soda_hip_plan* plan, const soda_hip_slab* slab, void* comm
         hi_edge = last_own - send_up;
       }
       if (!rc) {
-        rc = exchange((char*)dst);        // beside the interior sweep
+        rc = exchange((char*)dst, static_messages());        // beside the interior sweep
         count += 1;
         pending = true;
       }
@@ -1854,6 +2089,14 @@ int soda_hip_run_slab(soda_hip_plan* plan, const soda_hip_slab* slab, void* comm
   if (rc) return give_up(rc);
   *result = src;
   if (exchanges) *exchanges = count;
+  return 0;
+}
+
+// how many (kernel, box) pairs of the plan run a MEASURED (chunk, workgroups per CU)
+// instead of the kernel's calibrated one (soda_hip_plan_tune's streaming step)
+int soda_hip_plan_tuned_streams(const soda_hip_plan* plan, int* n) {
+  if (!plan || !n) return fail(SODA_HIP_ERR_NULL_ARGUMENT, "NULL argument");
+  *n = (int)plan->tuned_stream.size();
   return 0;
 }
 

@@ -193,11 +193,12 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
     '      fprintf(*error_report, "ERROR: ncclCommInitAll failed\\n");\n'
     '      return SODA_HIP_ERR_NO_DEVICE;\n    }\n  }\n')
   w('  std::vector<int> status(ngpu, 0);\n')
-  # Every rank derives the SAME exchange period from global figures before anything is
-  # sent (soda_hip_slab_exchange = the rule of runtime/dist.py: SlabPlan); a rank that
-  # fails during set-up is seen by all at a rendezvous in front of the first message,
-  # and one that fails later aborts every communicator so that no peer stays blocked
-  # in ncclRecv.
+  # Every rank derives the SAME exchange period and the same cuts from global figures
+  # before anything is sent; a rank that fails during set-up is seen by all at a
+  # rendezvous in front of the first message, and the thread of one that fails later
+  # aborts EVERY rank's communicator, once (ncclCommAbort is local to a rank: aborting
+  # the peers' own communicators is what takes them out of ncclRecv; the library is told
+  # to leave the communicator alone, soda_hip_slab.abort_on_error = 0 - one owner).
   w('  std::mutex gate; std::condition_variable gate_cv; int arrived = 0; '
     'bool setup_failed = false, aborted = false;\n')
   w('  auto rendezvous = [&](bool ok) {\n'
@@ -216,7 +217,8 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
   w('    soda_hip_module* module = nullptr;\n    soda_hip_plan* plan = nullptr;\n')
   w('    void *a = nullptr, *b = nullptr, *c = nullptr, *result = nullptr;\n')
   w('    soda_hip_slab slab;\n    memset(&slab, 0, sizeof slab);\n')
-  w('    int64_t local[4] = {1, 1, 1, 1}, ghost_lo = 0, ghost_hi = 0, own = 0;\n')
+  w('    int64_t local[4] = {1, 1, 1, 1}, in_at = 0, res_first = 0, res_last = 0, '
+    'res_at = 0, own = 0;\n')
   w('    size_t row_bytes = 0;\n')
   w('    rc = soda_hip_set_device(rank % count);\n')
   w('    if (!rc) rc = soda_hip_module_load_file(blob, &module);\n')
@@ -239,14 +241,21 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
     'base * 15) exchange -= %d;\n' % (deepest, deepest))
   w('      if (exchange > iterate) exchange = iterate;\n')
   w('      if (exchange < 1) exchange = 1;\n')
-  w('      // never deeper than the smallest slab (all ranks compute the same value)\n')
-  w('      rc = soda_hip_slab_exchange(rows, ngpu, lo[last], hi[last], exchange, &exchange);\n')
+  # slabs re-cut to the shrinking valid box every super-step (include/soda_hip.h:
+  # SODA_HIP_SLAB_CUT_RECUT) unless the environment asks for the static cut
+  w('      slab.cut = getenv("SODA_HIP_SLAB_STATIC_CUT") ? SODA_HIP_SLAB_CUT_STATIC : '
+    'SODA_HIP_SLAB_CUT_RECUT;\n')
+  w('      slab.abort_on_error = 0;   // abort_all below owns every communicator\n')
+  w('      // static cut: never deeper than the smallest slab (all ranks compute the same value)\n')
+  w('      if (slab.cut == SODA_HIP_SLAB_CUT_STATIC)\n')
+  w('        rc = soda_hip_slab_exchange(rows, ngpu, lo[last], hi[last], exchange, &exchange);\n')
   w('      slab.exchange = ngpu > 1 ? exchange : iterate;\n')
   # the order of exchange and sweeps: serial unless the environment asks for the
   # bands-first order (include/soda_hip.h: SODA_HIP_SLAB_BANDS_FIRST)
   w('      slab.order = getenv("SODA_HIP_SLAB_BANDS_FIRST") ? SODA_HIP_SLAB_BANDS_FIRST : '
     'SODA_HIP_SLAB_SERIAL;\n')
-  w('      if (!rc) rc = soda_hip_slab_extent(plan, &slab, local, &ghost_lo, &ghost_hi);\n')
+  w('      if (!rc) rc = soda_hip_slab_layout(plan, &slab, iterate, local, &in_at, &res_first, '
+    '&res_last, &res_at);\n')
   w('      row_bytes = (size_t)in->elem_size;\n')
   w('      for (int d = 0; d < last; ++d) row_bytes *= (size_t)in->extent[d];\n')
   w('      const size_t bytes = row_bytes * (size_t)local[last];\n')
@@ -257,7 +266,7 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
   w('      if (!rc) rc = soda_hip_memset(a, 0, bytes, nullptr);\n')
   w('      if (!rc) rc = soda_hip_memset(b, 0, bytes, nullptr);\n')
   w('      if (!rc) rc = soda_hip_memset(c, 0, bytes, nullptr);\n')
-  w('      if (!rc) rc = soda_hip_memcpy_h2d((char*)a + ghost_lo * row_bytes, '
+  w('      if (!rc) rc = soda_hip_memcpy_h2d((char*)a + in_at * row_bytes, '
     'in->host + slab.own_first * row_bytes, own * row_bytes, nullptr);\n')
   w('      if (!rc) rc = soda_hip_stream_synchronize(nullptr);\n')
   w('    }\n')
@@ -269,9 +278,6 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
   w('    if (go) {\n')
   w('      rc = soda_hip_run_slab(plan, &slab, comms[rank], a, b, c, iterate, '
     'nullptr, &result, nullptr);\n')
-  w('      if (rc && ngpu > 1) {\n')
-  w('        // soda_hip_run_slab has aborted this rank\'s communicator before returning\n')
-  w('        std::lock_guard<std::mutex> lock(gate);\n        comms[rank] = nullptr;\n      }\n')
   w('      if (!rc) rc = soda_hip_stream_synchronize(nullptr);\n')
   w('      if (rc) {\n')
   w('        fprintf(*error_report, "ERROR: GPU %d: %s: %s\\n", rank, '
@@ -280,16 +286,19 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
   w('      }\n')
   w('      if (!rc) {\n')
   w('        // only the valid interior goes back to the caller (host.py:838-899)\n')
-  w('        std::vector<uint8_t> stage(own * row_bytes);\n')
-  w('        rc = soda_hip_memcpy_d2h(stage.data(), (char*)result + ghost_lo * row_bytes, '
-    'own * row_bytes, nullptr);\n')
+  w('        // the rows of the result this rank holds (a re-cut run: its share of the rows '
+    'still valid)\n')
+  w('        const int64_t held = res_last - res_first;\n')
+  w('        std::vector<uint8_t> stage((size_t)(held > 0 ? held : 0) * row_bytes + 1);\n')
+  w('        if (held > 0) rc = soda_hip_memcpy_d2h(stage.data(), (char*)result + res_at * '
+    'row_bytes, held * row_bytes, nullptr);\n')
   w('        if (!rc) rc = soda_hip_stream_synchronize(nullptr);\n')
   w('        int32_t mlo[4], mhi[4];\n')
   w('        soda_hip_plan_margins(plan, iterate, mlo, mhi);\n')
   w('        const int64_t es = in->elem_size;\n')
   w('        const int64_t x0 = mlo[0], x1 = in->extent[0] - mhi[0];\n')
   w('        const int64_t inner_rows = row_bytes / (in->extent[0] * es);\n')
-  w('        for (int64_t y = slab.own_first; !rc && x1 > x0 && y < slab.own_last; ++y) {\n')
+  w('        for (int64_t y = res_first; !rc && x1 > x0 && y < res_last; ++y) {\n')
   w('          if (y < mlo[last] || y >= rows - mhi[last]) continue;\n')
   w('          for (int64_t q = 0; q < inner_rows; ++q) {\n')
   if dim == 3:
@@ -300,7 +309,7 @@ def print_multi_gpu(spec, w, app, name_in, name_out, dim, deepest):
       'q2 >= in->extent[2] - mhi[2]) continue;\n')
   w('            const size_t off = (size_t)(q * in->extent[0] + x0) * es;\n')
   w('            memcpy(out->host + y * row_bytes + off, stage.data() + '
-    '(y - slab.own_first) * row_bytes + off, (size_t)(x1 - x0) * es);\n')
+    '(y - res_first) * row_bytes + off, (size_t)(x1 - x0) * es);\n')
   w('          }\n        }\n      }\n    }\n')
   w('    soda_hip_free(a); soda_hip_free(b); soda_hip_free(c);\n')
   w('    soda_hip_plan_destroy(plan);\n    soda_hip_module_unload(module);\n')

@@ -11,7 +11,7 @@ MAX_TENSORS = 16
 MAX_IO = 8
 MAX_WINDOWS = 64
 MAX_KERNELS = 32
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 KERNEL_STAGE = 0
 KERNEL_FUSED = 1
@@ -59,10 +59,12 @@ class Slab(ctypes.Structure):
               ('exchange', ctypes.c_int32),
               ('dims', ctypes.c_int64 * MAX_DIMS),
               ('own_first', ctypes.c_int64), ('own_last', ctypes.c_int64),
-              ('order', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+              ('order', ctypes.c_int32), ('cut', ctypes.c_int32),
+              ('abort_on_error', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 SLAB_SERIAL, SLAB_BANDS_FIRST = 0, 1
+SLAB_CUT_STATIC, SLAB_CUT_RECUT = 0, 1
 
 
 class Timing(ctypes.Structure):
@@ -143,6 +145,9 @@ SIGNATURES = {
                                               ctypes.POINTER(ctypes.c_int)]),
     'soda_hip_slab_extent': (ctypes.c_int, [_VP, ctypes.POINTER(Slab), _I64P, _I64P,
                                             _I64P]),
+    'soda_hip_slab_layout': (ctypes.c_int, [_VP, ctypes.POINTER(Slab), ctypes.c_int, _I64P,
+                                            _I64P, _I64P, _I64P, _I64P]),
+    'soda_hip_plan_tuned_streams': (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_int)]),
     'soda_hip_run_slab': (ctypes.c_int, [_VP, ctypes.POINTER(Slab), _VP, _VP, _VP, _VP,
                                          ctypes.c_int, _VP, _VPP,
                                          ctypes.POINTER(ctypes.c_int)]),

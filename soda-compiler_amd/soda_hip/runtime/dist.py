@@ -84,6 +84,25 @@ class SlabPlan:
     return lo, hi
 
 
+def _corrupt_received(rank):
+  """Test hook (SODA_HIP_TUNING=1 only, like the library's own): SODA_DIST_CORRUPT_GHOST=R
+  makes rank R damage one cell of the first rows it receives in every exchange - what the
+  self-check of bench_main must catch."""
+  if os.environ.get('SODA_HIP_TUNING') != '1':
+    return False
+  who = os.environ.get('SODA_DIST_CORRUPT_GHOST')
+  return who is not None and who.lstrip('-').isdigit() and int(who) == rank
+
+
+def _damage(rows):
+  # a cell in the middle of the middle row (plane): a cell at the grid's edge would feed
+  # only cells that leave the valid box anyway
+  block = rows[rows.shape[0] // 2]
+  while block.dim() > 1:
+    block = block[block.shape[0] // 2]
+  block[block.shape[0] // 2:block.shape[0] // 2 + 1] += 1
+
+
 def exchange_ghosts(array, plan, dist, backend_ops=None):
   """array: torch tensor of shape reversed(local_dims) (outer dim first).
   Fills the ghost rows from the neighbours' own rows."""
@@ -113,6 +132,10 @@ def exchange_ghosts(array, plan, dist, backend_ops=None):
   if ops:
     for req in dist.batch_isend_irecv(ops):
       req.wait()
+    if _corrupt_received(plan.rank):
+      received = [op.tensor for op in ops if op.op is dist.irecv]
+      if received:
+        _damage(received[0])
 
 
 class SerialSchedule:
@@ -351,6 +374,25 @@ class RecutPlan:
     return total
 
 
+def static_max_rows_per_iteration(dims, world, r_lo, r_hi, exchange, iterate):
+  """RecutPlan.max_rows_per_iteration for the static even cut: per super-step the rows
+  the busiest rank sweeps (own rows + ghost rows, minus what has left the valid box at a
+  global edge, minus one reach per iteration), summed over the run."""
+  rows = dims[-1]
+  plans = [SlabPlan(dims, r, world, r_lo, r_hi, exchange) for r in range(world)]
+  total, done = 0, 0
+  while done < iterate:
+    step = min(plans[0].exchange, iterate - done)
+    worst = 0
+    for p in plans:
+      lo = max(p.start - p.ghost_lo, done * r_lo)
+      hi = min(p.stop + p.ghost_hi, rows - done * r_hi)
+      worst = max(worst, sum(max(0, hi - lo - i * (r_lo + r_hi)) for i in range(1, step + 1)))
+    total += worst
+    done += step
+  return total
+
+
 def exchange_rows(array, plan, s, dist):
   """array: torch tensor of shape reversed(plan.local_dims).  The grouped send / recv
   of RecutPlan.messages(s)."""
@@ -371,6 +413,9 @@ def exchange_rows(array, plan, s, dist):
   if ops:
     for req in dist.batch_isend_irecv(ops):
       req.wait()
+    if recvs and _corrupt_received(plan.rank):
+      a, b = plan.local(recvs[0][1])
+      _damage(array[a:b])
 
 
 def run_recut(engine, plan, arrays, margins_of, dist, ghosts_ready=False, schedule=None):
@@ -597,6 +642,129 @@ class TimedSerialSchedule(SerialSchedule):
   exchange_ms = StreamSchedule.exchange_ms
 
 
+def make_plan(static, dims, rank, world, r_lo, r_hi, exchange, iterate):
+  """The static even cut (SlabPlan) or slabs re-cut every super-step (RecutPlan)."""
+  if static:
+    return SlabPlan(dims, rank, world, r_lo, r_hi, exchange)
+  return RecutPlan(dims, rank, world, r_lo, r_hi, exchange, iterate)
+
+
+def run_plan(engine, plan, arrays, iterate, margins_of, dist, schedule=None,
+             ghosts_ready=False):
+  if isinstance(plan, RecutPlan):
+    return run_recut(engine, plan, arrays, margins_of, dist, ghosts_ready=ghosts_ready,
+                     schedule=schedule)
+  return run_slab(engine, plan, arrays, iterate, margins_of, dist,
+                  ghosts_ready=ghosts_ready, schedule=schedule)
+
+
+def result_rows(plan):
+  """((first, last) global rows of the result this rank holds, their local offset)."""
+  if isinstance(plan, RecutPlan):
+    return plan.final_rows, plan.final_rows[0] - plan.base
+  return (plan.start, plan.stop), plan.ghost_lo
+
+
+def super_step_shapes(plan, iterate):
+  """[(first local row, rows, iterations)] of the whole-slab sweep of every super-step."""
+  if isinstance(plan, RecutPlan):
+    out = []
+    for (done, step), need in zip(plan.steps, plan.need):
+      if need[plan.rank]:
+        a, b = plan.local(need[plan.rank])
+        out.append((a, b - a, step))
+    return out
+  out, done = [], 0
+  while done < iterate:
+    step = min(plan.exchange, iterate - done)
+    out.append((0, plan.local_extent, step))
+    done += step
+  return out
+
+
+def check_dims(dims, world, reach, exchange, iterate):
+  """The small grid of the multi-rank self-check and its iteration count: the inner
+  extents capped (4096 columns; 256 x 256 planes), two and a half exchange periods of
+  iterations (or the whole run if shorter), enough rows that every rank still holds
+  valid rows at the end."""
+  it = max(1, min(iterate, 2 * exchange + max(1, exchange // 2)))
+  cap = 4096 if len(dims) == 2 else 256
+  inner = [min(int(n), cap) for n in dims[:-1]]
+  it = min([it] + [(n - 8) // (2 * reach) for n in inner if n > 8 + 2 * reach])
+  it = max(1, it)
+  rows = 2 * reach * it + world * (64 if len(dims) == 2 else 16)
+  return inner + [rows], it
+
+
+def multi_rank_check(torch, dist, program, spec, make_input, margin_table_of, rank, world,
+                     static, r_lo, r_hi, exchange, overlapped, dims, iterate, backend, dev):
+  """Runs the chosen (cut, exchange period, order) once on a small grid cut the same
+  way, gathers every rank's rows of the result on rank 0 and compares them, cell for
+  cell, with the same grid swept by rank 0 alone (HIP against HIP: the one-rank sweep is
+  what the parity suite checks against the oracle).  Returns the number of differing
+  cells of the valid box, the same on every rank.  The driver's scaling run is the only
+  time real RCCL with more than one rank executes this code; a ghost row that arrives
+  wrong must not yield a throughput figure."""
+  reach = max(r_lo, r_hi, 1)
+  cdims, cit = check_dims(dims, world, reach, exchange, iterate)
+  plan = make_plan(static, cdims, rank, world, r_lo, r_hi, exchange, cit)
+  engine = HipEngine(program, torch)
+  table = margin_table_of(cit)
+
+  def margins_of(k):
+    if k == 0:
+      return (0,) * spec['dim'], (0,) * spec['dim']
+    return table[k - 1]
+  own = torch.from_numpy(make_input(spec, cdims, rows=(plan.start, plan.stop))[0]).to(dev)
+  shape = tuple(reversed(plan.local_dims))
+  a, b, c = (torch.zeros(shape, dtype=own.dtype, device=dev) for _ in range(3))
+  a[plan.ghost_lo:plan.ghost_lo + plan.own].copy_(own)
+  order = (StreamSchedule if overlapped and world > 1 else TimedSerialSchedule)(
+      torch, host_sync=backend != 'nccl')
+  result, _ = run_plan(engine, plan, [a, b, c], cit, margins_of, dist, schedule=order)
+  # (the engine leaves final_only as the last piece set it)
+  program.set_out_final_only(False)
+  torch.cuda.synchronize()
+  (first, last), offset = result_rows(plan)
+  mine = result[offset:offset + (last - first)].contiguous()
+  signed = {'torch.uint16': torch.int16, 'torch.uint32': torch.int32}
+  wire = (lambda t: t.view(signed[str(t.dtype)]) if str(t.dtype) in signed else t)
+  differing = 0
+  if rank == 0:
+    whole_in = torch.from_numpy(make_input(spec, cdims)[0]).to(dev)
+    want = torch.zeros_like(whole_in)
+    program.sweep([whole_in.data_ptr()], [want.data_ptr()], cdims, cit,
+                  stream=torch.cuda.current_stream().cuda_stream)
+    got = torch.zeros_like(whole_in)
+    got[first:last].copy_(mine)
+    ops = []
+    for q in range(1, world):
+      (qa, qb), _ = result_rows(make_plan(static, cdims, q, world, r_lo, r_hi, exchange, cit))
+      if qb > qa:
+        ops.append(dist.P2POp(dist.irecv, wire(got)[qa:qb], q))
+    if ops:
+      if backend != 'nccl':
+        torch.cuda.synchronize()
+      for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    torch.cuda.synchronize()
+    lo, hi = table[cit - 1]
+    box = tuple(slice(lo[d], cdims[d] - hi[d]) for d in reversed(range(spec['dim'])))
+    differing = int((got[box] != want[box]).sum().item())
+    if got[box].numel() == 0:
+      differing = -1
+  elif last > first:
+    if backend != 'nccl':
+      torch.cuda.synchronize()
+    for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, wire(mine), 0)]):
+      req.wait()
+    torch.cuda.synchronize()
+  verdict = torch.tensor([differing], dtype=torch.int64,
+                         device=dev if backend == 'nccl' else 'cpu')
+  dist.broadcast(verdict, 0)
+  return int(verdict.item()), cdims, cit
+
+
 def bench_main(args, open_program, make_input, per_iteration_updates,
                roofline_block, schedule_text, cpu_baseline=None):
   """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`."""
@@ -633,6 +801,8 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
     start, stop = bounds[rank]
     smallest = min(b1 - b0 for b0, b1 in bounds)
     reach = max(r_lo, r_hi, 1)
+    # slabs re-cut to the shrinking valid box every super-step unless --static-cut
+    static = bool(getattr(args, 'static_cut', False))
     dt = program.in_dtypes[0]
     tdt = {'float32': torch.float32, 'float64': torch.float64,
            'uint16': torch.uint16, 'int16': torch.int16, 'uint8': torch.uint8,
@@ -654,8 +824,9 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
     # builds its slab (own rows + ITS ghost rows) as a view of three arrays sized for
     # the deepest ghost regions
     own_rows = torch.from_numpy(make_input(spec, dims, rows=(start, stop))[0]).to(dev)
-    deepest_plan = SlabPlan(dims, rank, world, r_lo, r_hi, max(e for e, _ in pairs))
-    full_shape = tuple(reversed(deepest_plan.local_dims))
+    extents = [make_plan(static, dims, rank, world, r_lo, r_hi, e, args.iterate).local_extent
+               for e in sorted({e for e, _ in pairs})]
+    full_shape = tuple(reversed(dims[:-1] + [max(extents)]))
     storage = [torch.zeros(full_shape, dtype=tdt, device=dev) for _ in range(3)]
     engine = HipEngine(program, torch)
     margin_table = specmod.iteration_margins(spec, args.iterate)
@@ -668,7 +839,7 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
     def setup(exchange, overlapped):
       """(plan, [a, b, c], order, step) of one candidate: a holds the own rows at
       level 0, ghost rows anything - every step exchanges them first."""
-      plan = SlabPlan(dims, rank, world, r_lo, r_hi, exchange)
+      plan = make_plan(static, dims, rank, world, r_lo, r_hi, exchange, args.iterate)
       a, b, c = (t[:plan.local_extent] for t in storage)
       a[plan.ghost_lo:plan.ghost_lo + plan.own].copy_(own_rows)
       order = (StreamSchedule if overlapped else TimedSerialSchedule)(
@@ -677,18 +848,23 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
       # Every exchange is inside the timed region, the level-0 one included: a step
       # starts from own rows only, as a fresh input would arrive.
       def step():
-        return run_slab(engine, plan, [a, b, c], args.iterate, margins_of, dist,
+        return run_plan(engine, plan, [a, b, c], args.iterate, margins_of, dist,
                         schedule=order)
       return plan, (a, b, c), order, step
 
     def tune_split(plan, arrays):
       # untimed: the candidate splits of a super-step on this rank's slab
       # (soda_hip_plan_tune; no communication inside)
+      # (a re-cut run sweeps a slightly smaller sub-array every super-step: each
+      # distinct shape is tuned - the tuned split is keyed by extents and iterations)
       if not getattr(args, 'no_tune', False) and args.iterate > 1:
         torch.cuda.synchronize()
-        program.tune([arrays[0].data_ptr()], [arrays[1].data_ptr()], plan.local_dims,
-                     min(plan.exchange, args.iterate),
-                     stream=torch.cuda.current_stream().cuda_stream)
+        row_bytes = arrays[0][0].numel() * arrays[0].element_size()
+        for first_row, rows, iterations in sorted(set(super_step_shapes(plan, args.iterate))):
+          program.tune([arrays[0].data_ptr() + first_row * row_bytes],
+                       [arrays[1].data_ptr() + first_row * row_bytes],
+                       plan.local_dims[:-1] + [rows], iterations,
+                       stream=torch.cuda.current_stream().cuda_stream)
 
     def reduce_max(seconds):
       t = torch.tensor(list(seconds), dtype=torch.float64,
@@ -715,7 +891,10 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
     # one untimed exchange in any case: RCCL builds its point-to-point channels
     # on first use (seconds), which must not land in a run started with --warmup 0
     plan, arrays, order, step = setup(*pairs[0])
-    exchange_ghosts(arrays[0], plan, dist)
+    if isinstance(plan, RecutPlan):
+      exchange_rows(arrays[0], plan, 0, dist)
+    else:
+      exchange_ghosts(arrays[0], plan, dist)
     table = None
     if len(pairs) > 1:
       tuned = set()
@@ -735,6 +914,26 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
       plan, arrays, order, step = setup(chosen['exchange'], chosen['overlapped'])
     overlap = order.overlapped
     a, b, c = arrays
+    # the chosen cut, period and order once on a small grid against rank 0 alone: a run
+    # whose rows arrive wrong prints no throughput (config.multi_rank_check)
+    torch.cuda.synchronize()
+    differing, check_grid, check_iterate = multi_rank_check(
+        torch, dist, program, spec, make_input,
+        lambda n: specmod.iteration_margins(spec, n), rank, world, static, r_lo, r_hi,
+        plan.exchange, overlap, dims, args.iterate, backend, dev)
+    if differing != 0:
+      if rank == 0:
+        import json
+        print(json.dumps(dict(metric='gcell_updates_per_s', value=None, n_gpus=world,
+                              error='multi-rank self-check failed',
+                              config=dict(multi_rank_check='%d cells differ' % differing,
+                                          multi_rank_check_grid=check_grid,
+                                          multi_rank_check_iterate=check_iterate,
+                                          exchange_every=plan.exchange,
+                                          exchange_overlapped=overlap,
+                                          slab_cut='static' if static else 'recut'))),
+              flush=True)
+      raise SystemExit(3)
     for _ in range(args.warmup):
       step()
     if table is None:
@@ -763,11 +962,16 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
       # this stream, priced on the valid updates of its OWN rows (the same
       # definition as at N = 1: ghost rows are redundant work and earn nothing)
       first = min(plan.exchange, args.iterate)
-      lo, hi = plan.valid_margins(0, margins_of)
-      timing = program.sweep_timed([a.data_ptr()], [b.data_ptr()], plan.local_dims,
+      first_row, rows, _ = super_step_shapes(plan, args.iterate)[0]
+      row_bytes = a[0].numel() * a.element_size()
+      first_dims = plan.local_dims[:-1] + [rows]
+      timing = program.sweep_timed([a.data_ptr() + first_row * row_bytes],
+                                   [b.data_ptr() + first_row * row_bytes], first_dims,
                                    first, warmup=1, repeats=3)
-      sched = program.schedule(plan.local_dims, first)
-      updates = per_iteration_updates(spec, dims, first, rows=(plan.start, plan.stop))
+      sched = program.schedule(first_dims, first)
+      out_rows = (plan.cuts[0][rank], plan.cuts[0][rank + 1]) \
+          if isinstance(plan, RecutPlan) else (plan.start, plan.stop)
+      updates = per_iteration_updates(spec, dims, first, rows=out_rows)
       result = dict(
           metric='gcell_updates_per_s', value=valid / per_step / 1e9,
           unit='Gcell-updates/s', n_gpus=world, steps=args.steps,
@@ -779,6 +983,10 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
               args.app, dt.name, 'x'.join(map(str, dims)), args.iterate),
                       app=args.app, dims=dims, iterate=args.iterate,
                       parallelism='outer-dim slabs x%d' % world,
+                      multi_rank_check='bit-exact',
+                      multi_rank_check_grid='x'.join(map(str, check_grid)),
+                      multi_rank_check_iterate=check_iterate,
+                      slab_cut='static' if static else 'recut every super-step',
                       exchange_every=plan.exchange, exchanges_per_step=exchanges,
                       exchange_ms_per_step=exchange_ms,
                       exchange_overlapped=overlap,
@@ -789,22 +997,23 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
                       exchange_candidates_ms=table or [],
                       compute_only_ms_per_step=compute_only * 1e3,
                       ghost_rows=[plan.exchange * r_lo, plan.exchange * r_hi],
+                      local_rows=plan.local_extent,
                       super_step_schedule=schedule_text(sched),
                       valid_cell_updates=valid, nominal_cell_updates=nominal,
                       nominal_gcell_updates_per_s=nominal / per_step / 1e9,
                       effective_GBps=valid * abytes / per_step / 1e9,
                       device=host.device_info(local_rank)['arch']),
           roofline=roofline_block(spec, program, sched, updates, timing,
-                                  plan.local_dims, first))
+                                  first_dims, first))
       if cpu_baseline is not None and getattr(args, 'cpu_seconds', 0) > 0:
         # the CPU figure beside every point of the curve: the same
         # whole-grid workload on this host's cores, timed by rank 0 while the other
         # ranks wait at the barrier below - outside the timed region
         result['cpu_baseline'] = cpu_baseline(spec, dims, args.cpu_seconds)
       result['roofline']['note'] = (
-          'rank 0, first super-step of %d iterations on its %d own rows + %d ghost '
-          'rows; updates counted on own rows only' % (
-              first, plan.own, plan.ghost_lo + plan.ghost_hi))
+          'rank 0, first super-step of %d iterations on %d rows (%d of them its own '
+          'output rows, on which the updates are counted)' % (
+              first, rows, out_rows[1] - out_rows[0]))
     # rank 0 has timed its dominant kernel meanwhile: leave together
     torch.cuda.synchronize()
     dist.barrier()

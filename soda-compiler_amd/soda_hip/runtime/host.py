@@ -284,6 +284,13 @@ class Program:
         self.handle, self._ptr_array(in_ptrs), self._ptr_array(out_ptrs),
         self._dims(dims), iterate, vlo, vhi, stream))
 
+  def tuned_streams(self):
+    """How many (kernel, box) pairs run a MEASURED (chunk length, workgroups per CU)
+    instead of the kernel's calibrated pair (soda_hip_plan_tuned_streams)."""
+    n = ctypes.c_int()
+    capi.check(capi.lib().soda_hip_plan_tuned_streams(self.handle, ctypes.byref(n)))
+    return n.value
+
   def set_split(self, dims, iterate, depths):
     """Fixes the split of `iterate` into fused depths for these extents, in launch
     order; an empty list gives the choice back to the scheduler

@@ -12,7 +12,12 @@
 //              rows may be overwritten only after the copy).
 // ncclGroupStart/End batch operations exactly as the callers use them: all sends of
 // a group are posted before any receive blocks, so an open chain of any length
-// cannot deadlock.  Built by tests/test_gpu_parity.py with -Wl,-soname,librccl.so and
+// cannot deadlock.  ncclCommAbort is LOCAL, as RCCL's is: it fails the pending and later
+// operations of the communicator it is given and of no other - a caller that wants its
+// peers unblocked aborts THEIR communicators too (which a one-process driver can).  An
+// aborted communicator's memory is not released here (another thread may be inside an
+// operation on it; RCCL handles that internally, a test library can simply leak).
+// Built by tests/test_gpu_parity.py with -Wl,-soname,librccl.so and
 // loaded before libsoda_hip resolves "librccl.so" (the loader then hands this object
 // back by its soname); it is never on a product path.
 #include <hip/hip_runtime.h>
@@ -45,6 +50,7 @@ struct World {
 struct Comm {
   World* world;
   int rank;
+  bool aborted = false;     // under world->m
 };
 
 struct Op {
@@ -91,8 +97,8 @@ int flush() {
     {
       std::unique_lock<std::mutex> lock(w->m);
       auto& queue = w->box[{op.peer, op.comm->rank}];
-      w->cv.wait(lock, [&] { return w->aborted || !queue.empty(); });
-      if (queue.empty()) { rc = kSystemError; continue; }
+      w->cv.wait(lock, [&] { return op.comm->aborted || !queue.empty(); });
+      if (op.comm->aborted || queue.empty()) { rc = kSystemError; continue; }
       msg = queue.front();
       queue.pop_front();
     }
@@ -116,7 +122,7 @@ int flush() {
     World* w = entry.second.comm->world;
     {
       std::unique_lock<std::mutex> lock(w->m);
-      w->cv.wait(lock, [&] { return w->aborted || msg->copied; });
+      w->cv.wait(lock, [&] { return entry.second.comm->aborted || msg->copied; });
       if (!msg->copied) { rc = kSystemError; continue; }   // (message stays queued: leaked)
     }
     if (msg->failed || hipStreamWaitEvent(entry.second.stream, msg->done, 0) != hipSuccess)
@@ -134,6 +140,10 @@ int enqueue(bool send, void* buf, size_t count, int datatype, int peer, void* co
   if (!comm || !buf || datatype < 0 || datatype > 9) return kInvalidArgument;
   Comm* c = (Comm*)comm;
   if (peer < 0 || peer >= c->world->n || peer == c->rank) return kInvalidArgument;
+  {
+    std::lock_guard<std::mutex> lock(c->world->m);
+    if (c->aborted) return kSystemError;
+  }
   t_ops.push_back(Op{send, buf, count * width[datatype], peer, c, stream});
   return t_depth > 0 ? kSuccess : flush();
 }
@@ -167,17 +177,29 @@ int ncclCommInitAll(void** comms, int n, const int* /*devices*/) {
   if (!comms || n < 1) return kInvalidArgument;
   World* w = new World;
   w->n = w->alive = n;
-  for (int r = 0; r < n; ++r) comms[r] = new Comm{w, r};
+  for (int r = 0; r < n; ++r) comms[r] = new Comm{w, r, false};
   return kSuccess;
 }
 static int release(void* comm, bool abort) {
   if (!comm) return kInvalidArgument;
   Comm* c = (Comm*)comm;
   World* w = c->world;
+  if (abort) {
+    {
+      std::lock_guard<std::mutex> lock(w->m);
+      if (c->aborted) {
+        fprintf(stderr, "rccl stand-in: communicator of rank %d aborted twice\n", c->rank);
+        w->aborted = true;      // (kept as a flag tests can read: a double abort happened)
+        return kInvalidArgument;
+      }
+      c->aborted = true;
+    }
+    w->cv.notify_all();
+    return kSuccess;            // nothing freed: see the header comment
+  }
   bool last;
   {
     std::lock_guard<std::mutex> lock(w->m);
-    if (abort) w->aborted = true;
     last = --w->alive == 0;
   }
   w->cv.notify_all();
@@ -187,6 +209,13 @@ static int release(void* comm, bool abort) {
 }
 int ncclCommDestroy(void* comm) { return release(comm, false); }
 int ncclCommAbort(void* comm) { return release(comm, true); }
+// test instrumentation: did anybody abort a communicator a second time?
+int rccl_standin_double_abort(void* comm) {
+  if (!comm) return -1;
+  World* w = ((Comm*)comm)->world;
+  std::lock_guard<std::mutex> lock(w->m);
+  return w->aborted ? 1 : 0;
+}
 // test instrumentation: how much went through (proves the exchange ran)
 int rccl_standin_traffic(void* comm, long long* messages, long long* bytes) {
   if (!comm) return kInvalidArgument;

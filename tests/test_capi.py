@@ -64,13 +64,21 @@ def test_struct_layouts_match_the_header(lib, tmp_path):
       '  printf("%zu %zu %zu %zu %zu\\n", sizeof(soda_hip_kernel), sizeof(soda_hip_window),\n'
       '         sizeof(soda_hip_program), sizeof(soda_hip_slab), sizeof(soda_hip_timing));\n' +
       ''.join('  printf("%%zu\\n", offsetof(soda_hip_kernel, %s));\n' % f for f in fields) +
+      ''.join('  printf("%%zu\\n", offsetof(soda_hip_slab, %s));\n' % f
+              for f, _ in capi.Slab._fields_) +
       '  return 0;\n}\n')
   exe = tmp_path / 'layout'
   subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
   out = subprocess.check_output([str(exe)], text=True).split()
   assert [int(v) for v in out[:5]] == [ctypes.sizeof(t) for t in (
       capi.KernelDesc, capi.Window, capi.ProgramDesc, capi.Slab, capi.Timing)]
-  assert [int(v) for v in out[5:]] == [getattr(capi.KernelDesc, f).offset for f in fields]
+  assert [int(v) for v in out[5:5 + len(fields)]] == [getattr(capi.KernelDesc, f).offset
+                                                      for f in fields]
+  # the slab descriptor grew in ABI 8 (cut, abort_on_error): every field where C has it
+  assert [int(v) for v in out[5 + len(fields):]] == [getattr(capi.Slab, f).offset
+                                                     for f, _ in capi.Slab._fields_]
+  assert [f for f, _ in capi.Slab._fields_][-4:] == ['order', 'cut', 'abort_on_error',
+                                                     'reserved']
 
 
 def test_null_arguments_are_errors_not_crashes(lib):

@@ -686,6 +686,52 @@ def test_generated_cpp_host_multi_gpu_entry_with_several_ranks(tmp_path, app, di
   assert os.path.basename(standin) == 'librccl.so'
 
 
+def test_generated_multi_gpu_host_with_a_failing_rank(tmp_path):
+  """The failure path of the generated `<app>_multi_gpu`: rank 1 of three is made
+  to fail at its second super-step (SODA_HIP_FAIL_RANK, a hook behind SODA_HIP_TUNING).  Its
+  thread aborts every communicator once - the library leaves them alone
+  (soda_hip_slab.abort_on_error = 0): one owner, nothing aborted twice - the peers come out
+  of their exchanges with an error, the program ends with a non-zero status instead of
+  hanging, and the stand-in has seen no second abort of any communicator."""
+  import subprocess
+  import sys
+  from conftest import ROOT
+  standin = build_rccl_standin(tmp_path)
+  sodac = os.path.join(ROOT, 'soda-compiler_amd', 'sodac')
+  csrc = os.path.join(ROOT, 'soda-compiler_amd', 'csrc')
+  src = tmp_path / 'jacobi2d_host.cpp'
+  subprocess.check_call([sys.executable, sodac,
+                         os.path.join(ROOT, 'tests', 'samples', 'jacobi2d.soda'),
+                         '--hip-host-cpp', str(src)])
+  exe = tmp_path / 'jacobi2d_host'
+  subprocess.check_call(['g++', '-std=c++17', '-O1', '-fopenmp', '-ffp-contract=off',
+                         '-DSODA_HIP_MAIN', '-DSODA_HIP_MULTI_GPU',
+                         '-D__HIP_PLATFORM_AMD__', '-I', '/opt/rocm/include',
+                         '-I', os.path.join(ROOT, 'include'), str(src), '-L', csrc,
+                         '-lsoda_hip', '-L', os.path.dirname(standin), '-lrccl', '-lpthread',
+                         '-Wl,-rpath,' + csrc, '-Wl,-rpath,' + os.path.dirname(standin),
+                         '-Wl,-rpath,/opt/rocm/lib', '-o', str(exe)])
+  blob = os.path.join(gpu_util.BLOBS, 'jacobi2d.hsaco')
+  base = dict(os.environ, SODA_ITERATE='200', SODA_GPUS='3',
+              SODA_HIP_REHEARSE_RANKS_ON_ONE_GPU='1',
+              LD_LIBRARY_PATH=os.path.dirname(standin) + ':' +
+              os.environ.get('LD_LIBRARY_PATH', ''))
+  for extra in ({}, {'SODA_HIP_SLAB_STATIC_CUT': '1'}, {'SODA_HIP_SLAB_BANDS_FIRST': '1'}):
+    r = subprocess.run([str(exe), blob, '700', '1500'], capture_output=True, text=True,
+                       timeout=300, env=dict(base, SODA_HIP_TUNING='1', SODA_HIP_FAIL_RANK='1',
+                                             SODA_HIP_FAIL_SUPERSTEP='1', **extra))
+    assert r.returncode != 0, r.stdout[-500:]
+    assert 'injected failure of rank 1 at super-step 1' in r.stderr, r.stderr[-2000:]
+    assert 'aborted twice' not in r.stderr and 'INFO: PASS!' not in r.stderr
+    # every rank reported: the failing one and the two whose exchanges were cut short
+    assert r.stderr.count('ERROR: GPU') == 3, r.stderr[-2000:]
+  # without the hook the same binary passes (the static cut as well as the default)
+  for extra in ({}, {'SODA_HIP_SLAB_STATIC_CUT': '1'}):
+    r = subprocess.run([str(exe), blob, '700', '1500'], capture_output=True, text=True,
+                       timeout=300, env=dict(base, **extra))
+    assert r.returncode == 0 and 'INFO: PASS!' in r.stderr, r.stderr[-2000:]
+
+
 def test_run_slab_c_entry_with_one_rank():
   """soda_hip_run_slab / soda_hip_slab_extent (the slab driver below Python) with
   world = 1: same result as a plain sweep; a slab thinner than its ghost regions
@@ -1344,8 +1390,33 @@ def test_run_slab_with_two_and_three_ranks_over_the_rccl_standin(tmp_path, app, 
                             iterate, exchange, order)
 
 
+@pytest.mark.parametrize('app,dims,world,iterate,exchange,order', [
+    ('jacobi2d', (1300, 900), 2, 70, 24, 0),
+    ('jacobi2d', (700, 1500), 3, 100, 60, 0),
+    ('skew2d', (900, 800), 3, 30, 8, 0),          # one-sided-ish window: the cuts drift
+    ('jacobi2d', (700, 1600), 4, 200, 48, 0),
+    ('jacobi2d', (700, 1600), 4, 200, 48, 1),     # bands first
+    ('jacobi2d', (1300, 2400), 2, 130, 44, 1),
+    ('skew2d', (900, 1200), 3, 50, 12, 1),
+    # cfg5's proportions: 48-plane slabs, 64 iterations - with the static cut the first and
+    # last ranks run out of valid planes after 48; here every rank keeps a quarter of what
+    # is left, and rows change owner every super-step
+    ('jacobi3d', (160, 160, 192), 4, 64, 8, 0),
+    ('jacobi3d', (160, 160, 192), 4, 64, 16, 1),
+    # a period longer than the slabs are thick: partners beyond the nearest rank
+    ('jacobi2d', (600, 400), 4, 150, 120, 0)])
+def test_run_slab_recut_over_the_rccl_standin(tmp_path, app, dims, world, iterate, exchange,
+                                              order):
+  """soda_hip_slab.cut = SODA_HIP_SLAB_CUT_RECUT below the C ABI: every super-step the rows
+  its output level defines are cut evenly again, ghost rows and rows changing owner travel
+  in one group.  The ranks' rows of the result tile the final valid range and equal the
+  oracle bit for bit, in both orders."""
+  run_slab_over_the_standin(tmp_path, build_rccl_standin(tmp_path), app, dims, world,
+                            iterate, exchange, order, cut='recut')
+
+
 def run_slab_over_the_standin(tmp_path, standin, app, dims, world, iterate, exchange,
-                              order):
+                              order, cut='static'):
   """soda_hip_run_slab - the C slab driver: ncclSend / ncclRecv inside one group per
   super-step on the caller's stream, then the sweep - with world > 1.  RCCL refuses two
   ranks on one GPU and this box has one, so the ranks are host threads over a
@@ -1359,7 +1430,8 @@ def run_slab_over_the_standin(tmp_path, standin, app, dims, world, iterate, exch
   r = subprocess.run(
       [sys.executable, os.path.join(ROOT, 'tests', 'rccl_standin_worker.py'), standin,
        app, 'x'.join(map(str, dims)), str(world), str(iterate), str(exchange),
-       str(tmp_path), str(order)], capture_output=True, text=True, timeout=600)
+       str(tmp_path), str(order)] + (['cut=recut'] if cut == 'recut' else []),
+      capture_output=True, text=True, timeout=600)
   assert r.returncode == 0, r.stderr[-2000:]
   spec = gpu_util.load_spec(app, iterate=iterate)
   dt = np.dtype(specmod.NUMPY_NAME[spec['inputs'][0]['c_type']])
@@ -1369,29 +1441,52 @@ def run_slab_over_the_standin(tmp_path, standin, app, dims, world, iterate, exch
   orc = gpu_util.make_oracle(gpu_util.load_spec(app))
   want = orc.run([full], iterate=iterate)[spec['outputs'][0]]
   got = np.zeros_like(want)
+  held = []
   for rank in range(world):
     first, last, period, count, messages, nbytes = map(int, open(
         os.path.join(tmp_path, 'rank%d.txt' % rank)).read().split())
     got[first:last] = np.load(os.path.join(tmp_path, 'rank%d.npy' % rank))
+    held.append((first, last))
     assert count == -(-iterate // period)
   sl = orc.valid_slices(tuple(dims), iterate)
   assert want[sl].size > 0 and np.array_equal(got[sl], want[sl])
   r_lo, r_hi = spec['radius']['lo'][-1], spec['radius']['hi'][-1]
   row_bytes = int(np.prod(dims[:-1])) * dt.itemsize
+  if cut == 'recut':
+    # the ranks' rows tile the rows still valid, as evenly as they divide, and the rows
+    # that travelled are the ones RecutPlan (the Python driver's geometry) lists
+    from soda_hip.runtime import dist as sdist
+    assert held[0][0] == iterate * r_lo and held[-1][1] == dims[-1] - iterate * r_hi
+    assert all(a[1] == b[0] for a, b in zip(held, held[1:]))
+    assert max(b - a for a, b in held) - min(b - a for a, b in held) <= 1
+    plans = [sdist.RecutPlan(list(dims), r, world, r_lo, r_hi, period, iterate)
+             for r in range(world)]
+    assert held == plans[0].final
+    sent = [rows for p in plans for i in range(len(p.steps)) for _, rows in p.messages(i)[0]]
+    assert messages == len(sent) > 0
+    assert nbytes == sum(b - a for a, b in sent) * row_bytes
+    return
   # per exchange and interior boundary: period * r_lo rows up and period * r_hi down
   # (a one-sided window sends nothing one way)
   assert messages == count * (world - 1) * ((r_lo > 0) + (r_hi > 0))
   assert nbytes == count * (world - 1) * period * (r_lo + r_hi) * row_bytes
 
 
-@pytest.mark.parametrize('order,fail_rank,fail_at', [(0, 1, 1), (1, 0, 1), (1, 2, 0)])
+@pytest.mark.parametrize('order,fail_rank,fail_at,options', [
+    (0, 1, 1, []), (1, 0, 1, []), (1, 2, 0, ['cut=recut']),
+    (0, 1, 1, ['abort=lib']), (1, 2, 1, ['abort=lib', 'cut=recut'])])
 def test_a_rank_that_fails_mid_run_does_not_leave_its_peers_blocked(tmp_path, order,
-                                                                    fail_rank, fail_at):
-  """soda_hip_run_slab aborts the communicator before it returns an error (a failed
-  launch, allocation or exchange), so the neighbours' ncclRecv fail instead of waiting for
-  rows that will never come: with one rank made to fail at a given super-step
-  (SODA_HIP_FAIL_RANK / _SUPERSTEP, a test hook behind SODA_HIP_TUNING) every rank of a
-  three-rank group returns an error within the time limit, in both orders."""
+                                                                    fail_rank, fail_at,
+                                                                    options):
+  """A rank that fails after the first message (a failed launch, allocation or exchange;
+  here SODA_HIP_FAIL_RANK / _SUPERSTEP, a test hook behind SODA_HIP_TUNING) must not leave
+  its peers waiting in ncclRecv for rows that will never come.  ncclCommAbort is LOCAL to a
+  rank (the stand-in's is too), so what unblocks the peers is the driver of all ranks of the
+  process aborting every communicator once (the worker's abort_all = the generated
+  `<app>_multi_gpu`'s); with soda_hip_slab.abort_on_error the library has aborted the
+  failing rank's own before returning, and the driver must leave that one alone.  Every
+  rank of a three-rank group returns an error within the time limit, in both orders and
+  both cuts, and no communicator is aborted twice."""
   import subprocess
   import sys
   from conftest import ROOT
@@ -1399,7 +1494,7 @@ def test_a_rank_that_fails_mid_run_does_not_leave_its_peers_blocked(tmp_path, or
   r = subprocess.run(
       [sys.executable, os.path.join(ROOT, 'tests', 'rccl_standin_worker.py'), standin,
        'jacobi2d', '700x1500', '3', '200', '48', str(tmp_path), str(order),
-       'expect-failure'], capture_output=True, text=True, timeout=240,
+       'expect-failure'] + options, capture_output=True, text=True, timeout=240,
       env=dict(os.environ, SODA_HIP_TUNING='1', SODA_HIP_FAIL_RANK=str(fail_rank),
                SODA_HIP_FAIL_SUPERSTEP=str(fail_at)))
   assert r.returncode == 0, r.stderr[-2000:]
@@ -1407,9 +1502,51 @@ def test_a_rank_that_fails_mid_run_does_not_leave_its_peers_blocked(tmp_path, or
   assert len(lines) == 3
   for rank, text in enumerate(lines):
     assert text.split()[0] == str(rank) and 'soda_hip_run_slab' in text, lines
-    assert 'communicator aborted' in text, lines
+    if rank != fail_rank:     # the peers' exchange failed on THEIR aborted communicator
+      assert 'communicator aborted' in text, lines
   assert 'injected failure of rank %d at super-step %d' % (fail_rank, fail_at) in \
       lines[fail_rank]
+  # the library's own abort happens exactly when asked for
+  assert ('(communicator aborted)' in lines[fail_rank]) == ('abort=lib' in options)
+  assert open(os.path.join(tmp_path, 'double_abort.txt')).read().strip() == '0'
+  assert 'aborted twice' not in r.stderr
+
+
+def test_run_slab_checks_its_arguments_before_anything_is_sent():
+  """A bad `iterate`, order, cut or geometry is an error of the call, found before the first
+  message: it is returned without touching the communicator (a poisoned pointer here: any
+  use would crash), even with abort_on_error set (a caller that forgot to zero a
+  new field must not lose its communicator over it)."""
+  import ctypes
+  from soda_hip.runtime import capi
+  lib = capi.lib()
+  prog = gpu_util.open_prebuilt('jacobi2d')
+  try:
+    slab = capi.Slab()
+    slab.rank, slab.world, slab.reach_lo, slab.reach_hi, slab.exchange = 0, 2, 1, 1, 8
+    slab.dims[0], slab.dims[1] = 512, 400
+    slab.own_first, slab.own_last = 0, 200
+    slab.abort_on_error = 1
+    poison = ctypes.c_void_p(0xdead0000)
+    buf = host.DeviceArray(512 * 300 * 4)
+    result = ctypes.c_void_p()
+
+    def run(iterate):
+      return lib.soda_hip_run_slab(prog.handle, ctypes.byref(slab), poison, buf.ptr, buf.ptr,
+                                   buf.ptr, iterate, None, ctypes.byref(result), None)
+    assert run(0) == -8 and 'iterate' in lib.soda_hip_last_error().decode()
+    slab.order = 7
+    assert run(4) == -8 and 'order' in lib.soda_hip_last_error().decode()
+    slab.order, slab.cut = 0, 9
+    assert run(4) == -8 and 'cut' in lib.soda_hip_last_error().decode()
+    slab.cut, slab.exchange = 0, 0
+    assert run(4) == -8
+    slab.exchange, slab.cut, slab.own_last = 8, capi.SLAB_CUT_RECUT, 150
+    assert run(4) == -8 and 'even' in lib.soda_hip_last_error().decode()
+    assert 'communicator aborted' not in lib.soda_hip_last_error().decode()
+    buf.free()
+  finally:
+    prog.close()
 
 
 def test_bench_py_as_the_driver_launches_it_for_two_gpus():
@@ -1445,6 +1582,11 @@ def test_bench_py_as_the_driver_launches_it_for_two_gpus():
   assert c['dims'] == [4096, 3000] and c['iterate'] == 120
   assert c['exchanges_per_step'] >= 1 and c['exchange_every'] >= 1
   assert c['ghost_rows'] == [c['exchange_every'], c['exchange_every']]
+  # before the timed region the chosen cut, period and order ran once on a small grid and
+  # every rank's rows equalled the one-rank sweep of rank 0 (a wrong ghost row prints no
+  # throughput: test_bench_py_refuses_a_run_whose_ghost_rows_arrive_wrong)
+  assert c['multi_rank_check'] == 'bit-exact' and c['slab_cut'].startswith('recut')
+  assert c['multi_rank_check_grid'].startswith('4096x') and c['multi_rank_check_iterate'] >= 24
   # the exchange period and the order (serial / overlapped) are the fastest of the
   # candidates timed during warm-up, and the table is on the line
   table = c['exchange_candidates_ms']
@@ -1470,6 +1612,45 @@ def test_bench_py_as_the_driver_launches_it_for_two_gpus():
   cpu = d['cpu_baseline']
   assert cpu['kind'] == 'port' and cpu['value'] > 0 and len(cpu['samples']) == 3
   assert c['super_step_schedule']
+
+
+@pytest.mark.parametrize('cut', ['recut', 'static'])
+def test_bench_py_refuses_a_run_whose_ghost_rows_arrive_wrong(cut):
+  """The N > 1 bench line verifies itself: with one cell of the rows rank 1 receives damaged
+  in every exchange (SODA_DIST_CORRUPT_GHOST, a hook that exists under SODA_HIP_TUNING=1
+  only) the self-check before the timed region finds differing cells, rank 0 prints a line
+  WITHOUT a value and every rank exits non-zero - the driver's scaling run is the first
+  time real RCCL moves these rows, and a wrong row must not yield a throughput."""
+  import socket
+  import subprocess
+  import sys
+  from conftest import ROOT
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
+         '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+         os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+         '--size', '4096', '1500', '--iterate', '60', '--cpu-seconds', '0',
+         '--no-exchange-tune', '--no-tune'] + (['--static-cut'] if cut == 'static' else [])
+  env = dict(os.environ, SODA_DIST_BACKEND='gloo', OMP_NUM_THREADS='2')
+  bad = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                       env=dict(env, SODA_HIP_TUNING='1', SODA_DIST_CORRUPT_GHOST='1'))
+  assert bad.returncode != 0
+  lines = [l for l in bad.stdout.splitlines() if l.startswith('{"metric"')]
+  assert len(lines) == 1, bad.stdout[-2000:] + bad.stderr[-2000:]
+  d = json.loads(lines[0])
+  assert d['value'] is None and d['error'] == 'multi-rank self-check failed'
+  assert d['config']['multi_rank_check'].endswith('cells differ')
+  assert int(d['config']['multi_rank_check'].split()[0]) > 0
+  # the hook is dead without SODA_HIP_TUNING=1: the same command then passes
+  good = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                        env=dict(env, SODA_DIST_CORRUPT_GHOST='1'))
+  assert good.returncode == 0, good.stderr[-2000:]
+  d = json.loads([l for l in good.stdout.splitlines() if l.startswith('{"metric"')][0])
+  assert d['config']['multi_rank_check'] == 'bit-exact' and d['value'] > 0
+  assert d['config']['slab_cut'].startswith(cut)
 
 
 def test_bench_py_for_the_three_dimensional_multi_gpu_config():
@@ -1509,6 +1690,7 @@ def test_bench_py_for_the_three_dimensional_multi_gpu_config():
       (row['exchange'], row['overlapped']) for row in table}
   assert c['exchanges_per_step'] == -(-64 // c['exchange_every'])
   assert 0 < c['compute_only_ms_per_step'] < 1.5 * d['ms_per_step']
+  assert c['multi_rank_check'] == 'bit-exact' and c['slab_cut'].startswith('recut')
   from soda_hip.codegen import spec as specmod
   valid = specmod.valid_cells(gpu_util.load_spec('jacobi3d', iterate=64), [160, 160, 192], 64)
   assert abs(d['value'] - valid / (d['ms_per_step'] * 1e-3) / 1e9) < 1e-6 * d['value']
@@ -1538,6 +1720,7 @@ def test_bench_py_one_rank_group_over_real_rccl():
   c = d['config']
   assert d['n_gpus'] == 1 and c['parallelism'] == 'outer-dim slabs x1'
   assert c['ghost_rows'] == [c['exchange_every'], c['exchange_every']]
+  assert c['multi_rank_check'] == 'bit-exact'
   assert c['exchange_choice'] == 'given' and c['exchange_candidates_ms'] == []
   assert 0 < c['compute_only_ms_per_step'] < 1.25 * d['ms_per_step']
   spec = gpu_util.load_spec('jacobi2d', iterate=60)

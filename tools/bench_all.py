@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Runs bench.py's single-GPU protocol for every sample program and BASELINE
 config; writes profiles/<tag>_all_samples.json and prints a markdown table."""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [

@@ -3,6 +3,10 @@
 (kernel_stream3d_blk.emit, stamps=<debug buffer>) sums s_memtime deltas per part of
 a step; this prints the average per step over all wavefronts that ran.
 usage: blk_stamps.py app N 'key=value,...'   (options of kernel.generate; flags= too)"""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd')]

@@ -22,6 +22,10 @@ step = launch time / (rounds x (chunk + fill rows)), from the library's own laun
 trace (SODA_HIP_LAUNCH_TRACE).
 
 usage: calibrate.py [app ...]      (default: every sample with deep kernels)"""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import json
 import os
 import re

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Parity of one .soda file against the oracle on the GPU box, per depth limit.
 usage: check_program.py file.soda HxW[xD] [iterate] [key=value,...]"""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd'), os.path.join(ROOT, 'tests')]

@@ -3,6 +3,10 @@
 usage: check_variant.py app 'key=value,...' [max depth]   (generate() options; with a
 max depth the sweeps use kernels of at most that depth: 1 = the depth-1 kernels alone, on
 more shapes)"""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd'), os.path.join(ROOT, 'tests')]

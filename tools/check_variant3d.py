@@ -2,6 +2,10 @@
 """Parity of a 3-D fused-kernel generator variant against the oracle on the GPU box:
 the block form alone (deep3d=blk) on ragged shapes, several iteration counts, every
 depth split the scheduler takes.  usage: check_variant3d.py app 'key=value,...'"""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd'), os.path.join(ROOT, 'tests')]

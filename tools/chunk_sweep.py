@@ -3,6 +3,10 @@
 lengths (one launch = `depth` iterations).  For the launcher's cost model.
 usage: chunk_sweep.py app 'WxH,WxH,...' 'depth;key=val,...;chunk,chunk,...' ...
   chunk 0 = the launcher's own choice.  Offline hipcc builds, as the blobs."""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os
 import sys
 import time

@@ -22,6 +22,10 @@ coalesced streaming read, so it is doubled; WRITE_SIZE is exact.  The rule was
 re-checked for 4-, 8- and 16-byte-per-lane copies with tools/pmc_calib.hip
 (512 MiB read -> FETCH_SIZE 256 MiB in all three; profiles/r02_pmc_calibration.txt).
 """
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import collections
 import csv
 import glob

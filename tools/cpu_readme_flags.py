@@ -3,6 +3,10 @@
 and NO optimisation flag (README.md:95-96); SURVEY.md 8(d) asks for that figure
 once on BASELINE cfg1 (blur 2000 x 100), next to the -O3 -march=native figure the
 bench reports.  Times the CPU oracle (the port of the emitted loop nest) both ways."""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os
 import sys
 import time

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Prints the two markdown tables of DESIGN.md section 6 from the committed
 profiles (profiles/<tag>_all_samples.json, <tag>_traffic.json + kernel times)."""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import json
 import os
 import sys

@@ -3,6 +3,10 @@
 generated `<app>(buffer_t...)` calls) on random shapes: outputs pre-filled with a
 marker, only each output's valid box may change and must equal the oracle.
 usage: fuzz_buffers.py first_seed count"""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

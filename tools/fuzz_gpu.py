@@ -4,6 +4,10 @@ tests (tests/random_programs.py), HIP path (hiprtc) against the CPU oracle for e
 depth split.  Not a test: a hunt; a failing program goes into the committed families.
 usage: fuzz_gpu.py family first_seed count [generator options k=v,...]
 (family: plain ops struct cube deep)"""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os
 import sys
 import tempfile

@@ -2,6 +2,10 @@
 """Fuzzing run on the GPU box: the prebuilt sample programs on random array shapes
 (tiny, ragged, around the kernels' smallest-array limits) and iteration counts,
 against the CPU oracle.  usage: fuzz_shapes.py first_seed count"""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os
 import sys
 import time

@@ -3,6 +3,10 @@
 (tests/test_gpu_parity.py: test_slab_decomposition_with_the_hip_engine) on random
 grids, rank counts, exchange periods and iteration counts.
 usage: fuzz_slabs.py first_seed count"""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os
 import sys
 import time

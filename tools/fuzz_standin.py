@@ -4,6 +4,10 @@ stand-in with random programs, grids, rank counts (2-4), exchange periods, itera
 and BOTH orders (serial, bands first) - own rows put together against the oracle, message
 and byte counts against the schedule (tests/test_gpu_parity.py: run_slab_over_the_standin).
 usage: fuzz_standin.py first_seed count"""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os
 import sys
 import tempfile

@@ -5,6 +5,10 @@ back-to-back DEPENDENT (instruction i+1 reads what instruction i wrote: such a p
 cannot issue in consecutive slots of one wavefront; at two wavefronts per SIMD that
 is what bounds a kernel whose cells were serialised on one accumulator).
 usage: isa_stats.py app iterate kernel-name 'key=value,...' ['flags=-mllvm -x']..."""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd')]

@@ -4,6 +4,10 @@ the block form only, the wave-pipelined form only): how often the scheduler's co
 model picks the faster kernel for a box, and what the best per-launch choice would
 give.  Uses the library's own per-launch events (SODA_HIP_LAUNCH_TRACE).
 usage: launch_compare.py app N iterate 'key=value,...' 'key=value,...' ..."""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == '--child':

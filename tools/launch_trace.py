@@ -5,6 +5,10 @@
   python3 tools/launch_trace.py DIR A
 prints the launches of the LAST sweep in order (kernel, µs, workgroups).  This is
 how the 2x anomalies of the XCD super-tile padding were found (docs/DESIGN_HISTORY.md 4.1b)."""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import csv
 import glob
 import os

@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
 """One-shot host-buffer call (H2D + warm-up + timed sweep + D2H) on the GPU box."""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import sys, time, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0]=[ROOT, ROOT+'/soda-compiler_amd', ROOT+'/tests']

@@ -7,6 +7,10 @@ boundary bands first, then the interior: dist.band_plan), which prices what
 hiding the exchange costs in compute.
 usage: slab_cost.py [app] [W] [H] ['E,max_depth[,split]' ...]
 """
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,6 +2,10 @@
 """Per-launch averages of the SQ counters tools/sq_counters.sh collected, by kernel,
 with the shares the DESIGN tables quote (VALU issue utilisation, where a wavefront
 spends its life).  usage: sq_counters.py <directory of pass*/ outputs>"""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import csv
 import glob
 import json

@@ -3,6 +3,10 @@
 kernel under SODA_HIP_CHUNK_ROWS = each value (0 = the launcher's own choice) and
 SODA_HIP_WGS_PER_CU caps, fastest of the library's per-launch events.
 usage: stream_chunk_sweep.py app N depth 'chunks' 'caps'   e.g. jacobi2d 16384 1 0,8,16,32 0,2"""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd'), os.path.join(ROOT, 'tests')]

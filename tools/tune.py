@@ -2,6 +2,10 @@
 """Times single launches of fused-kernel variants on the GPU box.
 usage: tune.py app N iterate 'depth,cols,chunk_rows,prefetch' ...
 """
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd'), os.path.join(ROOT, 'tests')]

@@ -3,6 +3,10 @@
 usage: tune3d.py app N iterate 'key=value,...' ...   (options of kernel.generate;
 wp_* go to the depth-4 wave-pipelined kernel).  Each variant is first compared
 with the oracle on a small ragged grid, then timed on N^3."""
+import sys as _sys
+if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
+  print(__doc__)
+  _sys.exit(0)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'soda-compiler_amd')]
