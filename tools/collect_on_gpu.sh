@@ -33,21 +33,32 @@ sobel2d|--app sobel2d --size 16384 16384 --iterate 1
 heat3d|--app heat3d --size 512 512 512 --iterate 20
 denoise2d|--app denoise2d --size 8192 8192 --iterate 1
 denoise3d|--app denoise3d --size 256 256 256 --iterate 1
+cfg2_5x20|--app jacobi2d --size 8192 8192 --iterate 100|5x20
+cfg2_mixed|--app jacobi2d --size 8192 8192 --iterate 100|2x24+2x20+1x12
+cfg2_4x24|--app jacobi2d --size 8192 8192 --iterate 100|4x24+1x4
 WL
+# (a third field = a GIVEN split: the tuning step settles on different splits of cfg2 from
+# box to box - 5x20 here, 2x24+2x20+1x12 on the driver's box in round 5 - and a traffic
+# entry speaks only for the schedule it was measured on (bench.py: profile_entry_matches),
+# so each of them gets its own passes)
 # The split of `iterate` a plain run settles on (soda_hip_plan_tune) is found once per
 # workload, without the profiler, and GIVEN to every counter pass (--split): under
 # --pmc the tuning step times its candidates with the counters' overhead on top and
 # settled on other splits (cfg2: 3x24+16+12 instead of 5x20), so a pass measured
 # launches the timed run does not have.
 : > $out/pmc_${tag}_splits.txt
-while IFS='|' read -r name wargs; do
-  split=$(python3 bench.py $wargs --steps 10 --warmup 5 --cpu-seconds 0 2>/dev/null | \
-          python3 -c "import sys, json; print(json.loads([l for l in sys.stdin if l.startswith('{')][-1])['config']['depth_schedule'])")
+while IFS='|' read -r name wargs given; do
+  if [ -n "$given" ]; then
+    split=$given
+  else
+    split=$(python3 bench.py $wargs --no-other-configs --steps 10 --warmup 5 --cpu-seconds 0 2>/dev/null | \
+            python3 -c "import sys, json; print(json.loads([l for l in sys.stdin if l.startswith('{')][-1])['config']['depth_schedule'])")
+  fi
   case "$split" in *x[0-9]*) : ;; *) split="" ;; esac     # per-stage schedules: nothing to fix
   echo "$name|$split" >> $out/pmc_${tag}_splits.txt
 done < $out/pmc_${tag}_workloads.txt
 split_of() { grep "^$1|" $out/pmc_${tag}_splits.txt | cut -d'|' -f2; }
-while IFS='|' read -r name wargs; do
+while IFS='|' read -r name wargs given; do
   sp=$(split_of $name)
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d $out/pmc_${tag}_${name}_$c -- \
@@ -58,7 +69,8 @@ while IFS='|' read -r name wargs; do
 done < $out/pmc_${tag}_workloads.txt
 # SQ counters (VALU issue utilisation, where a wavefront spends its life): three more
 # --pmc passes per workload (tools/sq_counters.sh), summarised per kernel
-while IFS='|' read -r name wargs; do
+while IFS='|' read -r name wargs given; do
+  [ -n "$given" ] && continue          # (the SQ counters of cfg2 come from its own entry)
   sp=$(split_of $name)
   bash tools/sq_counters.sh ${tag}_${name} $wargs ${sp:+--split $sp} > /dev/null 2>&1 || echo "sq $name FAILED"
   echo "sq $name done"

@@ -99,7 +99,8 @@ def main():
     commit = None
   entries = []
   with open(os.path.join(src, 'pmc_%s_workloads.txt' % tag)) as f:
-    workloads = [line.strip().split('|') for line in f if line.strip()]
+    # name|bench arguments[|given split] (tools/collect_on_gpu.sh)
+    workloads = [tuple(line.strip().split('|')[:2]) for line in f if line.strip()]
   for name, args in workloads:
     words = args.split()
     app = words[words.index('--app') + 1]
