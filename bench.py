@@ -156,15 +156,15 @@ def cpu_baseline(spec, dims, budget_s):
   cpus = orc.team_cpus(quota)
   pinned = len(cpus) == quota and orc.pin_threads(cpus) == 0
   try:
-    t, u = orc.time_iterations(inputs, 2, warmup=1)      # sizes the samples
-    per = t / 2
-    n = int(max(3, min(5000, budget_s / 4.0 / max(per, 1e-6))))
-    samples, seconds = [], 0.0
-    for k in range(4):
+    t, u = orc.time_iterations(inputs, 2, warmup=1)      # cold: sizes the discarded sample
+    n = int(max(3, min(5000, budget_s / 8.0 / max(t / 2, 1e-6))))
+    t, u = orc.time_iterations(inputs, n, warmup=1)      # discarded: sizes the three kept
+    samples, seconds = [], t
+    n = int(max(3, min(20000, budget_s * 0.75 / 3.0 / max(t / n, 1e-6))))
+    for _ in range(3):     # ~a quarter of the budget each: short samples are noisy ones
       t, u = orc.time_iterations(inputs, n, warmup=1)
       seconds += t
-      if k:                                              # the first one is discarded
-        samples.append(u / t / 1e9)
+      samples.append(u / t / 1e9)
   finally:
     if pinned:
       orc.unpin_threads(mask, quota)

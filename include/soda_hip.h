@@ -216,6 +216,24 @@ typedef struct soda_hip_kernel {
                          (jacobi2d 16384^2 depth 1: 436 -> 378 us with 16 rows, blur 226
                          -> 200, sobel2d 246 -> 212; profiles/r04_stream_chunk.txt).
                          0 = the launcher's own choice */
+  /* (ABI 8) */
+  int32_t edge_slack;   /* N > 0 (kernels with origin_align > 1 and xcd_tiles < 0: the 3-D
+                         block form): a tile computes N valid columns more than the
+                         tile[0] it stores (what rounding its width down to origin_align
+                         left over), and the FIRST and LAST tile of a row of tiles store
+                         them: the launcher starts the tiles at
+                           x0 = (box_lo[0] + N) rounded down to origin_align
+                         (up to N columns INSIDE the box: the first tile, its window moved N
+                         columns to the left, stores [box_lo[0], x0 + tile[0])), launches
+                           nx = max(1, ceil((box_hi[0] - x0 - N) / tile[0]))
+                         tiles along x (the last one stores up to box_hi[0] <= its start +
+                         tile[0] + N) and passes x0 in the upper 32 bits of param[1].  One
+                         tile that would have to stretch both ways (nx == 1 and box_hi[0] >
+                         x0 + tile[0]), or a box that ends before x0, starts at box_lo[0]
+                         rounded down instead.  A box of
+                         456 columns takes 4 tiles of 112 instead of 5 (jacobi3d 512^3 x200:
+                         boxes 464, 456, 336, 328, 240, 232 and 112 lose a tile column).  0 = tiles start
+                         at box_lo[0] rounded down and every tile stores tile[0] columns */
 } soda_hip_kernel;
 
 /* By-value argument of every generated kernel. */

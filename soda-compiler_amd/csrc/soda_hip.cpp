@@ -371,6 +371,7 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
                   desc.name, (long long)args.box_lo[d], (long long)args.box_hi[d], d,
                   (long long)args.dims[d]);
   for (int d = 0; d < 3; ++d) out->grid[d] = 1;
+  int64_t edge_origin = -1;      // soda_hip_kernel.edge_slack: where the tiles start along x
   if (dim > 3 && desc.kind != SODA_HIP_KERNEL_STAGE)
     return fail(SODA_HIP_ERR_INTERNAL, "kernel %s: only per-stage kernels take 4-D boxes",
                 desc.name);
@@ -461,6 +462,20 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
       out->resident = (long long)resident;
     }
     int64_t g = (extent + tile - 1) / tile;
+    if (d == 0 && desc.edge_slack > 0 && desc.origin_align > 1 && desc.xcd_tiles < 0 && dim == 3) {
+      // the first and the last tile of a row store the columns the alignment left over
+      // (include/soda_hip.h: edge_slack): tiles start up to `slack` columns inside the box
+      const int64_t slack = desc.edge_slack, lo = args.box_lo[0], hi = args.box_hi[0];
+      int64_t x0 = (lo + slack) - (lo + slack) % desc.origin_align;
+      if (x0 >= hi) x0 = lo - lo % desc.origin_align;     // a box narrower than the shift
+      int64_t nx = std::max<int64_t>(1, (hi - x0 - slack + tile - 1) / tile);
+      if (nx == 1 && hi > x0 + tile) {      // one tile cannot stretch both ways
+        x0 = lo - lo % desc.origin_align;
+        nx = std::max<int64_t>(1, (hi - x0 - slack + tile - 1) / tile);
+      }
+      edge_origin = x0;
+      g = nx;
+    }
     if (d > 0 && desc.kind == SODA_HIP_KERNEL_STAGE && (g > 65535 || dim > 3)) {
       // Per-stage kernels take one row (plane) per workgroup; past the 65535
       // limit of grid.y / grid.z - and for every 4-D box - the rows and planes are
@@ -497,6 +512,7 @@ int make_launch(const soda_hip_plan* plan, int k, const soda_hip_args& args,
       return fail(SODA_HIP_ERR_EXTENTS_TOO_LARGE, "grid of kernel %s would be %lld",
                   desc.name, (long long)(per * 8));
     out->args.param[1] = 1 | (1 << 16);
+    if (edge_origin >= 0) out->args.param[1] |= edge_origin << 32;
     out->args.param[2] = gx | (gy << 16);
     out->args.param[3] = per;
     out->grid[0] = (unsigned)(per * 8);

@@ -383,7 +383,7 @@ def print_code(spec, kernels, out, lowered=None):
       'k[%d].step_valu = %d; k[%d].step_bytes = %d; k[%d].step_ns_full = %d; '
       'k[%d].step_ns_one = %d; k[%d].stream_gbps = %d; k[%d].xcd_tiles = %d; '
       'k[%d].stream_wgs_per_cu = %d; k[%d].fade_lo_mib = %d; k[%d].fade_hi_mib = %d; '
-      'k[%d].stream_chunk = %d;\n' % (
+      'k[%d].stream_chunk = %d; k[%d].edge_slack = %d;\n' % (
           i, i, kd['name'], i,
           'SODA_HIP_KERNEL_FUSED' if kd['kind'] == 'fused' else 'SODA_HIP_KERNEL_STAGE',
           i, kd['depth'], i, kd['stage'], i, kd.get('fill_rows', 0),
@@ -393,7 +393,7 @@ def print_code(spec, kernels, out, lowered=None):
           i, kd.get('step_ns_one', 0), i, kd.get('stream_gbps', 0),
           i, kd.get('xcd_tiles', 0), i, kd.get('stream_wgs_per_cu', 0),
           i, kd.get('fade_lo_mib', 0), i, kd.get('fade_hi_mib', 0),
-          i, kd.get('stream_chunk', 0)))
+          i, kd.get('stream_chunk', 0), i, kd.get('edge_slack', 0)))
     w('  { static const int32_t b[] = %s, t[] = %s; for (int d = 0; d < 3; ++d) '
       'k[%d].block[d] = b[d]; for (int d = 0; d < 4; ++d) k[%d].tile[d] = t[d]; }\n'
       % (_array(kd['block']), _array(kd['tile']), i, i))

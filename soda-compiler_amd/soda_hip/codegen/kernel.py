@@ -77,7 +77,7 @@ BLOCK_3D_SHALLOW_DEPTHS = (1, 2)
 # in the wave-pipelined form): 392 vs 378 us per 512^3 launch.
 DEEP_3D_FORM = 'both'
 BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300, nt=4, mask_loads=1,
-                        wide_stores=2)
+                        wide_stores=2, edge=1)
 # The block form's input planes: through a two-slot LDS ring (LDS-direct loads, no
 # prefetch registers) where the program's edge rows leave the LDS for it, else one
 # plane ahead in registers.  Per depth-4 launch inside the 512^3 array of cfg5 (same
@@ -96,8 +96,11 @@ BLOCK_3D_OPTIONS = dict(stack=8, prefetch=1, vgpr_budget=300, nt=4, mask_loads=1
 # guarded copy of the row loop for the trips at a chunk's ends; round 4): cfg5 with this
 # form alone 4.81 -> 4.66 ms, per launch box 400 130.5 -> 125.6 us, 256 55.0 -> 48.8,
 # 224 42.8 -> 37.3 (profiles/r04_blk_lean_fill.txt)
+# edge: the first and last tile of a row store the 8 valid columns the 64-byte alignment
+# drops (kernel_stream3d_blk.emit; soda_hip_kernel.edge_slack): cfg5's boxes 464, 456, 336,
+# 328, 240, 232 and 112 lose a tile column (round 6)
 BLOCK_3D_RING_OPTIONS = dict(stack=8, prefetch=0, ring=2, vgpr_budget=300, nt=4,
-                             mask_loads=1, wide_stores=2, lean_fill=1)
+                             mask_loads=1, wide_stores=2, lean_fill=1, edge=1)
 # ... for programs light enough on arithmetic: jacobi3d (weight 7) 417 us per
 # depth-4 launch against 2 x 374 us at depth 2, heat3d (15) 622 us against
 # 2 x 411 us; heavier programs are VALU-bound at depth 2 already

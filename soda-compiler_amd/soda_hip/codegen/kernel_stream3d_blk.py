@@ -96,7 +96,7 @@ ALIGN_OUT = 16      # cells: output tiles start and end on 64-byte pieces
 
 def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
          vgpr_budget=250, ring=0, pairs=0, stamps=0, mask_loads=0, nt=0,
-         wide_stores=0, lean_fill=0):
+         wide_stores=0, lean_fill=0, edge=0):
   """Returns (text, kernel table entry).
 
   `prefetch` = input planes loaded ahead into REGISTERS (R*C VGPRs each);
@@ -178,7 +178,16 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   tile's values for them; 2 = only in the launches beyond the Infinity Cache (with the
   non-temporal instantiation).  A partial piece at a box's edge costs a masked write:
   cfg5 -2.5..-6 % under the bench protocol.  2 ships (not for packed pair-rows: heat3d
-  +3 %)."""
+  +3 %).
+  `edge` = 1: rounding the tile's width down to whole 64-byte pieces leaves `slack` valid
+  columns a tile computes and does not store (128 - 8 = 120 at depth 4, 112 stored).  The
+  FIRST and the LAST tile of a row of tiles store them (soda_hip_kernel.edge_slack): the
+  launcher starts the tiles up to `slack` columns inside the box (param[1] >> 32), the first
+  tile's window moves `slack` columns to the left, the last tile stores up to the box's
+  end - nx tiles cover 112 nx + 8 columns wherever the box starts instead of 112 nx minus
+  box_lo % 16.  cfg5: the boxes 464, 456, 336, 328, 240, 232 and 112 lose a tile column (45 -> 36,
+  24 -> 18, 15 -> 10, 4 -> 2 tiles per plane).  Interior tiles are untouched; the moved
+  window's edge pieces may be partial (one piece per row and side).  Ships."""
   if spec['dim'] != 3:
     raise NotFusable('3-D programs only')
   types = specmod.tensor_c_types(spec)
@@ -230,6 +239,8 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     w_out -= w_out % align_out
   else:
     align_out = C
+  slack = LANES * C - halo_lo - halo_hi - w_out if edge and align_out > C else 0
+  edge = int(slack > 0)
   TR = G * R
   y_lo, y_hi = lo[1], hi[1]
   r_out = TR - y_lo - y_hi
@@ -373,15 +384,18 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
         '  %s{ st_box_lo -= st_box_lo %% %d; st_box_hi += %d - 1; st_box_hi -= st_box_hi %% %d; '
         'if (st_box_hi > a.dims[0]) st_box_hi = a.dims[0]; }' % (
             'if (%s) ' % when if when else '', seg, seg, seg),
-        '  const i64 st_lo = xs > st_box_lo ? xs : st_box_lo;',
-        '  const i64 st_hi = xs + %d < st_box_hi ? xs + %d : st_box_hi;' % (w_out, w_out)]
+        '  const i64 st_lo = xs - lo_ext > st_box_lo ? xs - lo_ext : st_box_lo;',
+        '  const i64 st_hi = xs + %d + hi_ext < st_box_hi ? xs + %d + hi_ext : st_box_hi;' % (
+            w_out, w_out)]
   else:
     wide_stores = 0
     store_range = [
-        '  const i64 st_lo = xs > a.box_lo[0] ? xs : a.box_lo[0];',
-        '  const i64 st_hi = xs + %d < a.box_hi[0] ? xs + %d : a.box_hi[0];' % (w_out, w_out)]
+        '  const i64 st_lo = xs - lo_ext > a.box_lo[0] ? xs - lo_ext : a.box_lo[0];',
+        '  const i64 st_hi = xs + %d + hi_ext < a.box_hi[0] ? xs + %d + hi_ext : a.box_hi[0];' % (
+            w_out, w_out)]
   line('template <bool RAGGED%s>' % (', bool NT' if nt_auto else ''))
-  line('DEV void %s_band(const soda_hip_args& a, const i64 xs, const i64 yb, '
+  line('DEV void %s_band(const soda_hip_args& a, const i64 xs, const i64 lo_ext, '
+       'const i64 hi_ext, const i64 yb, '
        'const i64 wx, const i64 wy, const i64 z0, const i64 z1, const int wave, '
        'const int lane, %s (*edges)[%d][%d][%d][%d], %s (*in_ring)[%d][%d][%d]) {'
        % (name, T, slots, G + 2, edge_rows, LANES * C, T, G if ring else 1,
@@ -764,9 +778,21 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('  const unsigned block_x = (g % nsx) * SX + within % SX;')
   line('  const unsigned block_y = ((g / nsx) % nsy) * SY + within / SX;')
   line('  const unsigned block_z = g / (nsx * nsy);')
-  line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % align_out)
-  line('  const i64 xs = x_origin + (i64)block_x * %d;' % w_out)
-  line('  if (xs >= a.box_hi[0]) return;')
+  if edge:
+    # where the tiles start comes from the launcher (up to `slack` columns inside the box:
+    # soda_hip_kernel.edge_slack); the first tile of a row reaches back to the box's start
+    # with its window moved `slack` columns to the left, the last one stores up to its end
+    line('  const i64 x_origin = (i64)((unsigned long long)a.param[1] >> 32);')
+    line('  const i64 xs = x_origin + (i64)block_x * %d;' % w_out)
+    line('  if (xs >= a.box_hi[0]) return;')
+    line('  const bool shifted = block_x == 0 && a.box_lo[0] < xs;')
+    line('  const i64 lo_ext = shifted ? %d : 0;' % slack)
+    line('  const i64 hi_ext = block_x + 1 == nsx && !shifted ? %d : 0;' % slack)
+  else:
+    line('  const i64 x_origin = a.box_lo[0] - a.box_lo[0] %% %d;' % align_out)
+    line('  const i64 xs = x_origin + (i64)block_x * %d;' % w_out)
+    line('  if (xs >= a.box_hi[0]) return;')
+    line('  const i64 lo_ext = 0, hi_ext = 0;')
   line('  const i64 yb = a.box_lo[1] + (i64)block_y * %d - %d;' % (r_out, y_lo))
   line('  const i64 chunk = a.param[0] > 0 ? a.param[0] : %d;' % chunk_planes)
   line('  const i64 z0 = a.box_lo[2] + (i64)block_z * chunk;')
@@ -774,7 +800,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
   line('  const i64 z1 = z0 + chunk < a.box_hi[2] ? z0 + chunk : a.box_hi[2];')
   # a tile that would overhang the array is moved inside it: every load is
   # unguarded and the tile still stores only its own cells
-  line('  i64 wx = xs - %d;' % halo_lo)
+  line('  i64 wx = xs - %d - lo_ext;' % halo_lo)
   line('  if (wx + %d > a.dims[0]) wx = a.dims[0] - %d;' % (LANES * C, LANES * C))
   line('  if (wx < 0) wx = 0;')
   line('  i64 wy = yb;')
@@ -790,7 +816,7 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     line(text)
   line('  const bool partial = !(x >= st_lo && x + %d <= st_hi) && (%s);' % (
       C, ' || '.join('(x + %d >= st_lo && x + %d < st_hi)' % (c, c) for c in range(C))))
-  call = '%s_band<%%s>(a, xs, yb, wx, wy, z0, z1, wave, lane, edges, %s);' % (
+  call = '%s_band<%%s>(a, xs, lo_ext, hi_ext, yb, wx, wy, z0, z1, wave, lane, edges, %s);' % (
       name, 'in_ring' if ring else 'nullptr')
   if nt_auto:
     # a box (input + output) beyond the Infinity Cache: its stores bypass the caches
@@ -822,4 +848,6 @@ def emit(spec, depth, cols=2, rows=8, stack=8, chunk_planes=64, prefetch=0,
     entry['lean_fill'] = 1
   if wide_stores:
     entry['wide_stores'] = int(wide_stores)
+  if edge:
+    entry['edge_slack'] = int(slack)
   return '\n'.join(o) + '\n', entry

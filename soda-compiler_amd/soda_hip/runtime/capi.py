@@ -50,7 +50,7 @@ class KernelDesc(ctypes.Structure):
               ('xcd_tiles', ctypes.c_int32),
               ('stream_wgs_per_cu', ctypes.c_int32),
               ('fade_lo_mib', ctypes.c_int32), ('fade_hi_mib', ctypes.c_int32),
-              ('stream_chunk', ctypes.c_int32)]
+              ('stream_chunk', ctypes.c_int32), ('edge_slack', ctypes.c_int32)]
 
 
 class Slab(ctypes.Structure):

@@ -95,17 +95,17 @@ def _corrupt_received(rank):
 
 
 def _damage(rows):
-  # a cell in the middle of the middle row (plane): a cell at the grid's edge would feed
-  # only cells that leave the valid box anyway
-  if rows.is_cuda:      # (whatever the backend still has in flight for these rows)
-    import torch
-    torch.cuda.synchronize()
-  block = rows[rows.shape[0] // 2]
-  while block.dim() > 1:
-    block = block[block.shape[0] // 2]
-  block[block.shape[0] // 2:block.shape[0] // 2 + 1] += 1
+  # the middle cell of the FIRST and of the LAST row (plane) of the block: one of the two
+  # lies next to the rank's own rows.  (A cell at the grid's edge feeds only cells that
+  # leave the valid box anyway; and an averaging stencil damps a bump of 1.0 that lies 24
+  # rows away below one float32 ulp within 48 iterations - measured: bit-identical rows.)
   import sys
-  sys.stderr.write('soda_hip dist: TEST HOOK damaged one cell of %d received rows\n'
+  for k in {0, rows.shape[0] - 1}:
+    block = rows[k]
+    while block.dim() > 1:
+      block = block[block.shape[0] // 2]
+    block[block.shape[0] // 2:block.shape[0] // 2 + 1] += 1
+  sys.stderr.write('soda_hip dist: TEST HOOK damaged the first and last of %d received rows\n'
                    % rows.shape[0])
 
 

@@ -194,6 +194,7 @@ def kernel_descs(table):
     d.fade_lo_mib = int(k.get('fade_lo_mib', 0))
     d.fade_hi_mib = int(k.get('fade_hi_mib', 0))
     d.stream_chunk = int(k.get('stream_chunk', 0))
+    d.edge_slack = int(k.get('edge_slack', 0))
   return arr
 
 

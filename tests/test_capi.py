@@ -50,7 +50,7 @@ def test_abi_version_and_error_names(lib):
 def test_struct_layouts_match_the_header(lib, tmp_path):
   # soda_hip_args is what the generated kernels receive by value
   assert ctypes.sizeof(capi.BufferT) == 72          # legacy Halide buffer_t
-  assert ctypes.sizeof(capi.KernelDesc) == 96 + 4 * (3 + 3 + 4 + 1 + 3 + 2 + 3 + 1 + 3 + 1)
+  assert ctypes.sizeof(capi.KernelDesc) == 96 + 4 * (3 + 3 + 4 + 1 + 3 + 2 + 3 + 1 + 3 + 1 + 1)
   assert ctypes.sizeof(capi.Window) == 4 * (2 + 4 + 4)
   assert ctypes.sizeof(capi.ProgramDesc) == 4 * (4 + 16 + 8 + 1) + 64 * 40
   # ... and against the C compiler's view of include/soda_hip.h: size of every struct

@@ -631,3 +631,66 @@ def test_programs_the_round4_fuzzing_found(name, tmp_path):
   text, table = kernel.generate(spec)
   assert any(k.get('stack') for k in table), [k['name'] for k in table]
   kernel.compile_to_code_object(text, str(tmp_path / 'k.hsaco'))
+
+
+def test_edge_tiles_cover_every_box_exactly_once():
+  """soda_hip_kernel.edge_slack (3-D block form, round 6): the launcher's rule for where
+  the tiles of a row start and how many there are, and the kernel's rule for what the first
+  and the last of them store, restated here and checked against each other for every box
+  start and width: the stored ranges tile [box_lo, box_hi) exactly, every stored column is
+  one the tile's (possibly moved) window computes validly, and no box takes more tiles
+  than under the old rule (start at box_lo rounded down, every tile stores tile[0])."""
+  def launcher(lo, hi, tile, slack, align=16):          # soda_hip.cpp: make_launch
+    x0 = (lo + slack) - (lo + slack) % align
+    if x0 >= hi:
+      x0 = lo - lo % align
+    nx = max(1, -(-(hi - x0 - slack) // tile))
+    if nx == 1 and hi > x0 + tile:
+      x0 = lo - lo % align
+      nx = max(1, -(-(hi - x0 - slack) // tile))
+    return x0, nx
+
+  def kernel_ranges(lo, hi, dims0, x0, nx, tile, slack, halo, width=128):   # the entry
+    out = []
+    for bx in range(nx):
+      xs = x0 + bx * tile
+      if xs >= hi:
+        continue
+      shifted = bx == 0 and lo < xs
+      lo_ext = slack if shifted else 0
+      hi_ext = slack if bx + 1 == nx and not shifted else 0
+      wx = min(xs - halo - lo_ext, dims0 - width)
+      wx = max(wx, 0)
+      st = (max(xs - lo_ext, lo), min(xs + tile + hi_ext, hi))
+      valid = (wx + halo if wx > 0 else 0, wx + width - halo if wx + width < dims0 else dims0)
+      assert valid[0] <= st[0] and st[1] <= valid[1], (lo, hi, dims0, bx, st, valid)
+      out.append(st)
+    return out
+  saved = 0
+  for tile, slack, halo in ((112, 8, 4), (112, 12, 2)):      # depth 4; depths 1 and 2
+    for lo in range(halo, 70):
+      for n in list(range(1, 260)) + [328, 336, 344, 448, 456, 504]:
+        hi = lo + n
+        for dims0 in (hi + halo, hi + 77):
+          if dims0 < 128:
+            continue
+          x0, nx = launcher(lo, hi, tile, slack)
+          at = lo
+          for a, b in kernel_ranges(lo, hi, dims0, x0, nx, tile, slack, halo):
+            assert a == at and b > a
+            at = b
+          assert at == hi, (lo, hi, x0, nx)
+          old = -(-(n + lo % 16) // tile)
+          assert nx <= old
+          saved += old - nx
+  assert saved > 0
+  # cfg5: the boxes whose tile count per row drops
+  drops = [n for n in range(112, 505, 8)
+           if launcher(256 - n // 2, 256 + n // 2, 112, 8)[1] <
+           -(-(n + (256 - n // 2) % 16) // 112)]
+  assert drops == [112, 232, 240, 328, 336, 456, 464]
+  # ... and the shipped jacobi3d kernels carry the figure the launcher reads
+  spec = spec_of('jacobi3d', iterate=200)
+  slack = {k['name']: k.get('edge_slack', 0) for k in kernel.generate(spec)[1]}
+  assert slack['jacobi3d_fused_k4b'] == 8 and slack['jacobi3d_fused_k1b'] == 12
+  assert slack['jacobi3d_fused_k4'] == 0

@@ -170,7 +170,7 @@ def test_the_keys_the_verdict_reads_come_first():
 
 
 def test_cpu_baseline_is_pinned_and_its_description_fits_the_record():
-  """bench.py's cpu_baseline leg on a tiny grid: threads pinned one per core
+  """bench.py's cpu_baseline leg on a tiny grid: threads pinned one per core, spread over the mask
   (oracle/pin_threads.c), one discarded sample + three, the description within the 120
   characters the driver's record keeps, the caller's affinity restored."""
   from soda_hip import frontend
