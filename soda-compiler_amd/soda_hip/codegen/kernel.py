@@ -266,8 +266,11 @@ def calibration_key(entry, spec):
   run again."""
   import hashlib
   import json
+  # (edge_slack changes which tiles a launch has, not what a workgroup's step costs: the
+  # streamed loop is the same text with and without it)
   shape = {k: v for k, v in entry.items()
-           if k not in CALIBRATED_FIELDS + MEASURED_OVER_DEFAULT + ('step_valu', 'step_bytes')}
+           if k not in CALIBRATED_FIELDS + MEASURED_OVER_DEFAULT +
+           ('step_valu', 'step_bytes', 'edge_slack')}
   digest = hashlib.sha1(json.dumps(shape, sort_keys=True).encode()).hexdigest()[:12]
   return '%s/%s/%s' % (kernel_common.program_hash(spec)[:12], entry['name'], digest)
 
