@@ -73,6 +73,9 @@ def parse_args():
                        'for the whole run; default: the rows each super-step defines are cut '
                        'evenly again (the valid box shrinks every iteration: a static cut '
                        'idles the first and last ranks)')
+  ap.add_argument('--recut', action='store_true',
+                  help='N > 1: re-cut slabs, without timing the chosen exchange period and '
+                       'order under the static cut as well (the default keeps the faster cut)')
   ap.add_argument('--no-tune', action='store_true',
                   help='split `iterate` into fused depths by the calibrated model alone '
                        'instead of timing the candidate splits on this grid during '
