@@ -1244,6 +1244,74 @@ def test_slab_decomposition_with_the_hip_engine(app, dims, world, exchange, iter
   assert np.array_equal(got[sl], want[sl])
 
 
+@pytest.mark.parametrize('app,dims,world,exchange,iterate,bands', [
+    ('jacobi2d', (1500, 611), 3, 5, 17, False), ('jacobi2d', (1500, 611), 4, 24, 48, True),
+    ('jacobi2d', (900, 1400), 8, 48, 300, True),
+    # cfg5's proportions on 8 ranks: 20-plane slabs, 40 iterations - the valid range ends
+    # with 10 planes per rank, partners beyond the nearest rank
+    ('jacobi3d', (170, 150, 160), 8, 4, 40, False), ('jacobi3d', (170, 150, 160), 8, 8, 40, True),
+    ('heat3d', (140, 64, 90), 3, 12, 24, True), ('skew2d', (1100, 900), 4, 7, 21, True)])
+def test_recut_decomposition_with_the_hip_engine(app, dims, world, exchange, iterate, bands):
+  """Slabs re-cut every super-step (soda_hip.runtime.dist.RecutPlan) with the REAL kernels:
+  all ranks emulated on this one GPU - up to eight, more than processes may share it - the
+  rows of RecutPlan.messages copied by hand where RCCL would move them, the sweeps those of
+  run_recut (sub-arrays of the rows a rank reads, both outer sides declared valid; `bands`:
+  cut into RecutPlan.pieces, each piece written by its last launch only).  Covers what the
+  gloo tests cannot: soda_hip_sweep on those sub-arrays, wide 3-D planes whose first and
+  last tile columns store the edge columns, ranks whose share shrinks to a few planes."""
+  import torch
+  from soda_hip.codegen import spec as specmod
+  from soda_hip.runtime import dist as sdist
+  prog = program(app)
+  spec = prog.spec
+  dim = spec['dim']
+  full = np.random.default_rng(12).random(tuple(reversed(dims)), dtype=np.float32)
+  table = specmod.iteration_margins(spec, iterate)
+  zero = (tuple([0] * dim), tuple([0] * dim))
+  margins_of = lambda k: zero if k == 0 else table[k - 1]      # noqa: E731
+  engine = sdist.HipEngine(prog, torch)
+  r_lo, r_hi = spec['radius']['lo'][-1], spec['radius']['hi'][-1]
+  plans = [sdist.RecutPlan(list(dims), r, world, r_lo, r_hi, exchange, iterate)
+           for r in range(world)]
+  dev = torch.device('cuda', 0)
+  cur, nxt = [], []
+  for p in plans:
+    a = torch.full(tuple(reversed(p.local_dims)), float('nan'), dtype=torch.float32, device=dev)
+    a[p.ghost_lo:p.ghost_lo + p.own] = torch.from_numpy(full[p.start:p.stop]).to(dev)
+    cur.append(a)
+    nxt.append(torch.full_like(a, float('nan')))
+  try:
+    for s, (done, step) in enumerate(plans[0].steps):
+      for r, p in enumerate(plans):          # what exchange_rows() does over RCCL
+        for peer, rows in p.messages(s)[1]:
+          a0, a1 = p.local(rows)
+          b0, b1 = plans[peer].local(rows)
+          cur[r][a0:a1] = cur[peer][b0:b1]
+      for r, p in enumerate(plans):
+        lo, hi = (list(v) for v in margins_of(done))
+        lo[-1] = hi[-1] = 0
+        out = (p.cuts[s][r], p.cuts[s][r + 1])
+        pieces = p.pieces(s) if bands else None
+        todo = [(o, True) for o in pieces[0] + [pieces[1]]] if pieces else \
+            [(out, False)] if out[1] > out[0] else []
+        for (o0, o1), final_only in todo:
+          engine.sweep(cur[r], nxt[r], p.local_dims, step, lo, hi,
+                       rows=(o0 - step * r_lo - p.base, o1 + step * r_hi - p.base),
+                       final_only=final_only)
+      torch.cuda.synchronize()
+      cur, nxt = nxt, [torch.full_like(a, float('nan')) for a in nxt]
+  finally:
+    prog.set_out_final_only(False)
+  got = np.zeros_like(full)
+  for r, p in enumerate(plans):
+    (g0, g1), (l0, l1) = p.final_rows, p.local(p.final_rows)
+    got[g0:g1] = cur[r][l0:l1].cpu().numpy()
+  want = oracle(app).run([full], iterate=iterate)[spec['outputs'][0]]
+  sl = oracle(app).valid_slices(dims, iterate)
+  assert want[sl].size > 0
+  assert np.array_equal(got[sl], want[sl])
+
+
 @pytest.mark.parametrize('app,dims,world,iterate,exchange,mode', [
     ('jacobi2d', (1300, 900), 2, 70, 24, 'serial'),
     ('jacobi2d', (1300, 1500), 3, 100, 20, 'overlap'),

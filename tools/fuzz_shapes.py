@@ -37,6 +37,11 @@ for seed in range(first, first + count):
     w = int(rng.integers(1, 90)) if mode == 0 else int(rng.integers(60, 1500))
     h = int(rng.integers(1, 60)) if mode == 1 else int(rng.integers(20, 600))
     shape = (h, w)
+  elif rng.random() < 0.5:
+    # wide planes, few of them: the 3-D block form's tiles of 112 x 56 with one to four tile
+    # columns, every box start modulo 16 (round 6: the first and last tile of a row store
+    # the columns the alignment drops - soda_hip_kernel.edge_slack)
+    shape = (int(rng.integers(2, 48)), int(rng.integers(64, 150)), int(rng.integers(128, 480)))
   else:
     hi = 40 if rng.random() < 0.3 else 180
     shape = tuple(int(rng.integers(1, hi)) for _ in range(3))

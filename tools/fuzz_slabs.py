@@ -25,7 +25,7 @@ for seed in range(first, first + count):
   app = str(rng.choice(['jacobi2d', 'jacobi2d', 'skew2d', 'seidel2d', 'jacobi3d', 'heat3d']))
   spec = T.program(app).spec
   dim = spec['dim']
-  world = int(rng.integers(2, 6))
+  world = int(rng.integers(2, 9))
   iterate = int(rng.integers(1, 60 if dim == 2 else 16))
   exchange = int(rng.integers(1, iterate + 4))
   r = max(spec['radius']['lo'][-1], spec['radius']['hi'][-1])
@@ -38,11 +38,19 @@ for seed in range(first, first + count):
   lo, hi = specmod.iteration_margins(spec, iterate)[-1]
   if any(dims[d] - lo[d] - hi[d] < 2 for d in range(dim)) or dims[-1] // world < r:
     continue
+  # round 6: half the cases with slabs re-cut every super-step (up to 8 emulated ranks,
+  # whole sweeps or bands first)
+  recut = rng.random() < 0.5
+  bands = bool(rng.integers(0, 2))
   try:
-    T.test_slab_decomposition_with_the_hip_engine(app, dims, world, exchange, iterate)
+    if recut:
+      T.test_recut_decomposition_with_the_hip_engine(app, dims, world, exchange, iterate, bands)
+    else:
+      T.test_slab_decomposition_with_the_hip_engine(app, dims, world, exchange, iterate)
   except Exception as e:
     failures += 1
-    print('FAIL', app, dims, world, exchange, iterate, repr(e)[:200], flush=True)
+    print('FAIL', app, dims, world, exchange, iterate, 'recut' if recut else 'static', bands,
+          repr(e)[:200], flush=True)
   done += 1
   if done % 25 == 0:
     print('%d cases, %d failures, %.0f s' % (done, failures, time.time() - t0), flush=True)

@@ -39,14 +39,16 @@ with tempfile.TemporaryDirectory() as top:
       iterate = max(1, min(dims) // (2 * r) - 1)
     exchange = int(rng.integers(1, iterate + 3))
     order = int(rng.integers(0, 2))
+    cut = 'recut' if rng.random() < 0.6 else 'static'     # round 6: slabs re-cut every super-step
     case = os.path.join(top, 'c%d' % seed)
     os.makedirs(case)
     try:
-      T.run_slab_over_the_standin(case, standin, app, dims, world, iterate, exchange, order)
+      T.run_slab_over_the_standin(case, standin, app, dims, world, iterate, exchange, order,
+                                  cut=cut)
     except BaseException as e:   # noqa: BLE001 - counted and reported
       failures += 1
-      print('FAIL seed %d: %s %s world %d iterate %d exchange %d order %d: %s' % (
-          seed, app, dims, world, iterate, exchange, order, str(e)[:300]), flush=True)
+      print('FAIL seed %d: %s %s world %d iterate %d exchange %d order %d cut %s: %s' % (
+          seed, app, dims, world, iterate, exchange, order, cut, str(e)[:300]), flush=True)
     if (seed - first + 1) % 20 == 0:
       print('%d cases, %d failures, %.0f s' % (seed - first + 1, failures, time.time() - t0),
             flush=True)
