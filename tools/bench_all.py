@@ -27,7 +27,7 @@ for name, args in CASES:
   # run, 2.2 ms in a 30-step run)
   steps, warmup = ('3', '1') if 'cfg4' in name else ('30', '10')
   r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', steps,
-                      '--warmup', warmup, '--cpu-seconds', '3'] + args,
+                      '--warmup', warmup, '--cpu-seconds', '3', '--no-other-configs'] + args,
                      capture_output=True, text=True)
   line = [l for l in r.stdout.splitlines() if l.startswith('{"metric')]
   if not line:
