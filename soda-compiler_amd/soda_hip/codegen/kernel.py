@@ -114,7 +114,7 @@ ALIGN_FULL_MAX_WEIGHT = 40
 # generator options of the fused 2-D forms that `generate` passes through:
 # those both forms understand, and those only the wave-pipelined form has
 SHARED_2D_OPTIONS = ('skip_fill', 'vgpr_budget', 'max_period', 'align', 'waves_per_eu')
-WP_ONLY_OPTIONS = ('pairs', 'ring', 'split', 'prio')
+WP_ONLY_OPTIONS = ('pairs', 'ring', 'split', 'prio', 'seam_probe')
 
 HIPCC_FLAGS = ['-x', 'hip', '--offload-arch=gfx950', '--cuda-device-only',
                '--no-gpu-bundle-output', '-O3', '-ffp-contract=off',

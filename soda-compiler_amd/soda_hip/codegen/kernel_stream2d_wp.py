@@ -163,7 +163,7 @@ def packable(spec):
 
 def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
          max_period=12, vgpr_budget=120, skip_fill=1, pairs=0, align='none',
-         ring=0, waves_per_eu=0, split=None, prio=None):
+         ring=0, waves_per_eu=0, split=None, prio=None, seam_probe=0):
   """Returns (text, kernel table entry).
 
   pairs=2 (needs the ring): ONE strip of 2 x 64 x C columns per wavefront; a
@@ -190,6 +190,17 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   guarded per element, so strips that would overhang the array are moved inside
   it (they still store only their own columns) and the kernel declares the
   narrowest array it accepts (min_extent).
+
+  seam_probe=1 (wide form only; a TIMING PROBE, never shipped - tools/chunk_sweep.py
+  '24;seam_probe=1', profiles/r06_seam_probe.txt): what exchanging the x halo between
+  neighbouring strips instead of recomputing it would ADD per level-row, executed for real
+  but feeding nothing: at the start of a step one ds_read_b32 per level (the neighbour's
+  edge value of the row before, written before the barrier) and one wait; per level one
+  VALU operation that stands for inserting it into lane 0 / 63 behind the DPP shift, one
+  v_cndmask that picks this lane's edge column (column 0 in lane 0, column 2C-1 in lane 63:
+  two different registers) and one ds_write_b32.  Four wave-instructions per level-row on
+  top of 22; the results are the unchanged kernel's (the strips still overlap), so the
+  probe prices the cost side only - the gain side is 512 / 464 columns at depth 24.
 
   pairs=1 (float programs, see packable()): a wavefront streams TWO adjacent
   strips at once, element c of strip A and element c of strip B sharing one
@@ -333,6 +344,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
     line('        }')
 
   def emit_body(mine, guarded):
+    probed = [i for i in mine if i.role in ('compute', 'lds_out') or i.final] if seam_probe \
+        else []
     for u in range(period):
       line('      {  // unrolled step %d' % u)
       for inst in mine:
@@ -412,6 +425,22 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
           target = ('out_row[%d]' % c) if direct else \
               '%s[%d][%d]' % (inst.ident, slot(inst, u, 0), c)
           cell_assignment(stage, target, load, line, '        ')
+        if inst in probed:
+          k = probed.index(inst)
+          row = 'out_row' if direct else '%s[%d]' % (inst.ident, slot(inst, u, 0))
+          # the neighbour strip's edge value of the row before (written before the barrier):
+          # read, waited for and consumed in one go - an asm statement's outputs must be
+          # complete when it ends (a read left in flight past its statement is a register
+          # the compiler may have given to something else: the first version of this probe
+          # faulted), so the probe pays the LDS latency where a real implementation would
+          # issue the read a level ahead and pay a register for it
+          line('        { float seam_in;')
+          line('          asm volatile("ds_read_b32 %%0, %%1 offset:%d\\n\\ts_waitcnt lgkmcnt(0)" '
+               ': "=v"(seam_in) : "v"(seam_rd + %du));' % (k * 256, ((u + 1) % 2) * 2048))
+          line('          seam_acc += seam_in; }')
+          line('        { const float e = seam_first ? %s[0][0] : %s[%d][1];' % (row, row, C - 1))
+          line('          asm volatile("ds_write_b32 %%0, %%1 offset:%d" :: "v"(seam_wr + %du), '
+               '"v"(e)); }' % (k * 256, (u % 2) * 2048))
         if inst.role == 'lds_out' and pairs:
           for q in range(pieces):
             line('        { soda_f4 v;%s *(soda_f4*)&handoff[%d][%d][%d][%d][lane * 4] = v; }' % (
@@ -460,7 +489,10 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
        'const i64 xb, const i64 y0, const i64 y1, const int wave, const int lane,'
        % name)
   ring_dims = (P, LANES * C) if RS else (1, 1)
-  if pairs:
+  if pairs and seam_probe:
+    line('    float (*handoff)[2][%d][%d][%d], %s (*in_ring)[%d][%d], float* seam_lds) {'
+         % (S, pieces, LANES * 4, T_in, ring_dims[0], ring_dims[1]))
+  elif pairs:
     line('    float (*handoff)[2][%d][%d][%d], %s (*in_ring)[%d][%d]) {'
          % (S, pieces, LANES * 4, T_in, ring_dims[0], ring_dims[1]))
   else:
@@ -492,6 +524,15 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
   line('  const bool ragged = __builtin_amdgcn_ballot_w64(%s) != 0; (void)ragged;'
        % ' || '.join(parts))
   line('  const i64 steps = (y1 - y0) + %d;' % (L + geo['y_lo']))
+  if seam_probe:
+    # per wavefront 2 parities x 8 levels x 64 lanes of floats; a lane reads what lane 63 - l
+    # wrote (the other edge)
+    line('  float seam_acc = 0.0f;')
+    line('  const bool seam_first = lane == 0;')
+    line('  const unsigned seam_wr = (unsigned)(unsigned long long)seam_lds + wave * 4096u + '
+         'lane * 4u;')
+    line('  const unsigned seam_rd = (unsigned)(unsigned long long)seam_lds + wave * 4096u + '
+         '(63 - lane) * 4u;')
   prologue_steps = max(i.first_step for i in everything)
   prologue_steps = -(-prologue_steps // period) * period if skip_fill else 0
   for g, mine in enumerate(per_wave):
@@ -531,6 +572,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
       line('    __builtin_amdgcn_s_waitcnt(%d);  // no load may outlive the LDS'
            % vmcnt(0))
     line('  }')
+  if seam_probe:      # keeps the probe's values alive; never true
+    line('  if (seam_acc == 1.2345e30f) g_out[0] = seam_acc;')
   line('}')
   line('')
   occupancy = ''
@@ -547,6 +590,10 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
         T_in, max(1, groups - 1), S, LANES * C))
   line('  __attribute__((shared)) %s in_ring[%d][%d][%d];' % (
       T_in, RS if RS else 1, ring_dims[0], ring_dims[1]))
+  if seam_probe:
+    if not wide:
+      raise NotFusable('seam_probe: the wide packed form only')
+    line('  __attribute__((shared)) float seam_lds[%d];' % (groups * 1024))
   line('  const int lane = lane_id();')
   line('  const int wave = __builtin_amdgcn_readfirstlane('
        '__builtin_amdgcn_workitem_id_x() >> 6);')
@@ -571,7 +618,8 @@ def emit(spec, depth, cols=None, chunk_rows=256, prefetch=3, groups=4,
       line('  const i64 x = wx + lane * %d, xb = x + %d;' % (2 * C, C))
     else:
       line('  const i64 x = wx + lane * %d, xb = wxb + lane * %d;' % (C, C))
-    line('  %s_strip<true>(a, xs, x, xb, y0, y1, wave, lane, handoff, in_ring);' % name)
+    line('  %s_strip<true>(a, xs, x, xb, y0, y1, wave, lane, handoff, in_ring%s);' % (
+        name, ', seam_lds' if seam_probe else ''))
   else:
     line('  const i64 x = xs - %d + lane * %d;' % (geo['halo_lo'], C))
     line('  const i64 xb = x + %d;' % geo['w_out'])
