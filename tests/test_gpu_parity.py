@@ -1730,6 +1730,39 @@ def test_bench_py_refuses_a_run_whose_ghost_rows_arrive_wrong(cut):
   assert d['config']['slab_cut'].startswith(cut)
 
 
+def test_bench_py_falls_back_to_the_conservative_configuration():
+  """When the self-check fails for the configuration the warm-up chose, bench.py checks the
+  most conservative one in its place - static cut, serial order - and goes on with it only
+  if THAT is bit-exact, saying so on the line.  Here only the re-cut's exchanges are damaged
+  (SODA_DIST_CORRUPT_CUT=recut): the run ends with rc 0, slab_cut static, serial order, and
+  multi_rank_check names what failed."""
+  import socket
+  import subprocess
+  import sys
+  from conftest import ROOT
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  r = subprocess.run(
+      [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+       '--master-addr', '127.0.0.1', '--master-port', str(port),
+       os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+       '--size', '4096', '1500', '--iterate', '60', '--cpu-seconds', '0', '--no-tune',
+       '--recut'], capture_output=True, text=True, timeout=600,
+      env=dict(os.environ, SODA_DIST_BACKEND='gloo', OMP_NUM_THREADS='2', SODA_HIP_TUNING='1',
+               SODA_DIST_CORRUPT_GHOST='1', SODA_DIST_CORRUPT_CUT='recut'))
+  # (--recut: the warm-up does not get to prefer the static cut by timing; being told the
+  # cut is no reason to refuse the fallback - only --static-cut is already the fallback)
+  assert r.returncode == 0, r.stderr[-2000:]
+  d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0])
+  c = d['config']
+  assert d['value'] > 0 and c['slab_cut'] == 'static' and c['exchange_overlapped'] is False
+  assert c['multi_rank_check'].startswith('bit-exact with the static cut and the serial order')
+  assert 're-cut cut' in c['multi_rank_check'] and 'cells differ' in c['multi_rank_check']
+  assert 'self-check FAILED' in r.stderr
+
+
 def test_bench_py_for_the_three_dimensional_multi_gpu_config():
   """BASELINE cfg5 is an 8-GPU config (jacobi3d 512^3 x 200 in 64-plane slabs: the edge
   ranks' own planes leave the valid box after 64 iterations while the middle ranks go

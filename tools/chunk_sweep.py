@@ -2,7 +2,10 @@
 """Per-launch time of fused-kernel variants on several box shapes and chunk
 lengths (one launch = `depth` iterations).  For the launcher's cost model.
 usage: chunk_sweep.py app 'WxH,WxH,...' 'depth;key=val,...;chunk,chunk,...' ...
-  chunk 0 = the launcher's own choice.  Offline hipcc builds, as the blobs."""
+  chunk 0 = the launcher's own choice.  Offline hipcc builds, as the blobs.
+  keys `flags=-mllvm:-opt=value` (extra hipcc flags, ':' between words) and `noflags=1`
+  (without the per-program flags of the kernel text) are the compiler's, the rest the
+  generator's."""
 import sys as _sys
 if len(_sys.argv) > 1 and _sys.argv[1] in ('-h', '--help'):   # usage = the text above
   print(__doc__)
@@ -33,10 +36,16 @@ for variant in sys.argv[3:]:
                      iterate=max(depth, 16))
   spec = specmod.spec_from_stencil(st)
   t0 = time.time()
+  # flags=-mllvm:-amdgpu-sched-strategy=iterative-ilp -> extra hipcc flags; noflags=1 drops the
+  # per-program flags the kernel text records (an -mllvm option may be given only once)
+  flags = str(opts.pop('flags', '')).split(':') if opts.get('flags') else []
+  noflags = opts.pop('noflags', 0)
   text, table = kernel.generate(spec, depths=[depth], **opts)
+  if noflags:
+    text = '\n'.join(l for l in text.split('\n') if not l.startswith(kernel.FLAGS_MARK))
   path = '/tmp/sweep_%d.hsaco' % os.getpid()
   try:
-    kernel.compile_to_code_object(text, path)
+    kernel.compile_to_code_object(text, path, extra_flags=flags)
   except Exception as e:
     print(variant, 'COMPILE FAILED', str(e)[:200], flush=True)
     continue
