@@ -1767,7 +1767,7 @@ def test_bench_py_for_the_three_dimensional_multi_gpu_config():
   """BASELINE cfg5 is an 8-GPU config (jacobi3d 512^3 x 200 in 64-plane slabs: the edge
   ranks' own planes leave the valid box after 64 iterations while the middle ranks go
   on).  The driver's command line for it, rehearsed on this box's ONE GPU with four gloo
-  ranks and the same proportions (160 x 160 x 192, 64 iterations, 48-plane slabs): the line, the candidate
+  ranks and the same proportions (128 x 128 x 160, 52 iterations, 40-plane slabs): the line, the candidate
   table, the compute-only time, and nobody stalls on a rank whose boxes are empty."""
   import socket
   import subprocess
@@ -1781,7 +1781,7 @@ def test_bench_py_for_the_three_dimensional_multi_gpu_config():
       [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
        '4', '--master-addr', '127.0.0.1', '--master-port', str(port),
        os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '1', '--warmup', '0',
-       '--app', 'jacobi3d', '--size', '160', '160', '192', '--iterate', '64',
+       '--app', 'jacobi3d', '--size', '128', '128', '160', '--iterate', '52',
        '--cpu-seconds', '0', '--no-tune'],
       capture_output=True, text=True, timeout=900,
       env=dict(os.environ, SODA_DIST_BACKEND='gloo', OMP_NUM_THREADS='2'))
@@ -1790,7 +1790,7 @@ def test_bench_py_for_the_three_dimensional_multi_gpu_config():
   assert len(lines) == 1, r.stdout[-2000:]
   d = json.loads(lines[0])
   c = d['config']
-  assert d['n_gpus'] == 4 and c['dims'] == [160, 160, 192] and c['iterate'] == 64
+  assert d['n_gpus'] == 4 and c['dims'] == [128, 128, 160] and c['iterate'] == 52
   assert c['parallelism'] == 'outer-dim slabs x4' and d['scaling'] == 'strong'
   table = c['exchange_candidates_ms']
   # periods 4, 8, 16, 32 (1, 2, 4, 8 x the deepest 3-D kernel), serial and overlapped
@@ -1799,11 +1799,11 @@ def test_bench_py_for_the_three_dimensional_multi_gpu_config():
   assert [row['cut'] for row in table] == ['recut'] * 8 + ['static']
   assert (c['exchange_every'], c['exchange_overlapped']) in {
       (row['exchange'], row['overlapped']) for row in table}
-  assert c['exchanges_per_step'] == -(-64 // c['exchange_every'])
+  assert c['exchanges_per_step'] == -(-52 // c['exchange_every'])
   assert 0 < c['compute_only_ms_per_step'] < 1.5 * d['ms_per_step']
   assert c['multi_rank_check'] == 'bit-exact' and c['slab_cut'].split()[0] in ('recut', 'static')
   from soda_hip.codegen import spec as specmod
-  valid = specmod.valid_cells(gpu_util.load_spec('jacobi3d', iterate=64), [160, 160, 192], 64)
+  valid = specmod.valid_cells(gpu_util.load_spec('jacobi3d', iterate=52), [128, 128, 160], 52)
   assert abs(d['value'] - valid / (d['ms_per_step'] * 1e-3) / 1e9) < 1e-6 * d['value']
   assert d['roofline']['kernel'].startswith('jacobi3d_fused_k')
 
