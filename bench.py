@@ -157,7 +157,8 @@ def cpu_baseline(spec, dims, budget_s):
   orc.set_threads(quota)
   mask = os.sched_getaffinity(0)
   cpus = orc.team_cpus(quota)
-  pinned = len(cpus) == quota and orc.pin_threads(cpus) == 0
+  attempted = len(cpus) == quota
+  pinned = attempted and orc.pin_threads(cpus) == 0
   try:
     t, u = orc.time_iterations(inputs, 2, warmup=1)      # cold: sizes the discarded sample
     n = int(max(3, min(5000, budget_s / 8.0 / max(t / 2, 1e-6))))
@@ -169,7 +170,7 @@ def cpu_baseline(spec, dims, budget_s):
       seconds += t
       samples.append(u / t / 1e9)
   finally:
-    if pinned:
+    if attempted:        # (also after a partial failure: some threads may be pinned)
       orc.unpin_threads(mask, quota)
   samples.sort()
   median = samples[1]
