@@ -794,10 +794,16 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
     local_rank = local_rank % max(1, torch.cuda.device_count())
   torch.cuda.set_device(local_rank)
   capi.check(capi.lib().soda_hip_set_device(local_rank))
+  # a collective that never completes (a rank that died, a pairing that deadlocks) fails
+  # after this long instead of torch's ten minutes: nothing here waits longer than the CPU
+  # baseline rank 0 times while the others stand at a barrier (~12 s)
+  import datetime
+  patience = datetime.timedelta(seconds=int(os.environ.get('SODA_DIST_TIMEOUT_S', '240')))
   if backend == 'nccl':
-    dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank),
+                            timeout=patience)
   else:
-    dist.init_process_group(backend=backend)
+    dist.init_process_group(backend=backend, timeout=patience)
   try:
     program, spec = open_program(args.app, args.iterate, args.jit)
     program.set_max_depth(args.max_depth)
