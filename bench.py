@@ -57,6 +57,10 @@ def parse_args():
                        '1, 2, 4, 8 x the deepest fused kernel, timed during warm-up)')
   ap.add_argument('--cpu-seconds', type=float, default=12.0,
                   help='CPU baseline sample budget (0 = skip)')
+  ap.add_argument('--cpu-baseline-at-all-n', action='store_true',
+                  help='N > 1: rank 0 times the CPU baseline as well (by default it is on '
+                       'the N = 1 line only: it is a property of the host, and 12 s of every '
+                       'multi-GPU run would go into it)')
   ap.add_argument('--force-dist', action='store_true',
                   help='take the torch.distributed slab path even with 1 rank')
   ap.add_argument('--overlap', action='store_true',

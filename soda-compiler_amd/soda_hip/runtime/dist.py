@@ -1063,8 +1063,10 @@ def bench_main(args, open_program, make_input, per_iteration_updates,
                       device=host.device_info(local_rank)['arch']),
           roofline=roofline_block(spec, program, sched, updates, timing,
                                   first_dims, first))
-      if cpu_baseline is not None and getattr(args, 'cpu_seconds', 0) > 0:
-        # the CPU figure beside every point of the curve: the same
+      if cpu_baseline is not None and getattr(args, 'cpu_seconds', 0) > 0 and (
+          world == 1 or getattr(args, 'cpu_baseline_at_all_n', False)):
+        # the CPU figure is a property of the host, reported on the N = 1 line; with
+        # --cpu-baseline-at-all-n also beside the other points of the curve: the same
         # whole-grid workload on this host's cores, timed by rank 0 while the other
         # ranks wait at the barrier below - outside the timed region
         result['cpu_baseline'] = cpu_baseline(spec, dims, args.cpu_seconds)

@@ -1635,7 +1635,8 @@ def test_bench_py_as_the_driver_launches_it_for_two_gpus():
       [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
        '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
        os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-       '--size', '4096', '3000', '--iterate', '120', '--cpu-seconds', '2'],
+       '--size', '4096', '3000', '--iterate', '120', '--cpu-seconds', '2',
+       '--cpu-baseline-at-all-n'],
       capture_output=True, text=True, timeout=600,
       env=dict(os.environ, SODA_DIST_BACKEND='gloo', OMP_NUM_THREADS='2'))
   assert r.returncode == 0, r.stderr[-2000:]
@@ -1684,8 +1685,9 @@ def test_bench_py_as_the_driver_launches_it_for_two_gpus():
   assert abs(d['value'] - valid / (d['ms_per_step'] * 1e-3) / 1e9) < 1e-6 * d['value']
   rf = d['roofline']
   assert rf['kernel'].startswith('jacobi2d_fused_k') and 0 < rf['frac'] < 1.5
-  # the CPU figure stands beside every point of the curve: rank 0 times
-  # the oracle port on the whole grid AFTER the timed region, the others wait
+  # with --cpu-baseline-at-all-n the CPU figure stands beside this point of the curve too
+  # (by default it is on the N = 1 line only): rank 0 times the oracle port on the whole
+  # grid AFTER the timed region, the others wait
   cpu = d['cpu_baseline']
   assert cpu['kind'] == 'port' and cpu['value'] > 0 and len(cpu['samples']) == 3
   assert c['super_step_schedule']
